@@ -1,0 +1,136 @@
+/* zerovox_amd.h — C-ABI of the MI355X-native ZeroVox hot path (libzerovox_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers, sizes and status codes, no ggml / HIP / torch
+ * types.  Each entry point replaces one piece of the reference's C++ class API
+ * (/root/reference/src/zerovox.h, namespace ZeroVOX); the C++ facade with the reference's own
+ * class names and method signatures (zerovox.cpp_amd/csrc/zerovox.h) is a thin layer over it.
+ *
+ *   zv_model_load      <- ZeroVOXModel::ZeroVOXModel(fname)   src/zerovox.cpp:21-179 (GGUF KV ->
+ *                         hparams, weight upload, stage construction)
+ *   zv_encode          <- FS2Encoder::eval                    src/zerovox.h:191, src/fs2encoder.cpp:594-656
+ *   zv_decode          <- StyleTTSDecoder::eval               src/zerovox.h:323, src/stylettsdec.cpp:457-470
+ *   zv_vocode          <- HiFiGAN::eval                       src/zerovox.h:378, src/hifigan.cpp:358-377
+ *   zv_synthesize      <- ZeroVOXModel::eval                  src/zerovox.cpp:198-335 (three stages back to back)
+ *   zv_write_wav       <- ZeroVOXModel::write_wav_file        src/zerovox.cpp:337-391 (PCM16 mono RIFF)
+ *   zv_last_error      <- std::runtime_error / die_fmt / GGML_ASSERT messages (src/zerovox.h:435-455)
+ *
+ * Differences that are deliberate: the number of phonemes N and the number of frames
+ * T are run-time arguments (the reference fixes them at graph-build time: MAX_N_PHONEMES, max_seq_len);
+ * results for a given (N, T) are those of a reference instance built for exactly that (N, T) — there
+ * is no attention mask and InstanceNorm statistics run over all T frames (SURVEY Appx C-H2).
+ * Bad ids / sizes return ZV_ERR_ARG instead of aborting.
+ *
+ * Threading: calls on one zv_model are serialised by the caller (one HIP stream per model);
+ * several models per process are allowed (e.g. one per GPU).
+ */
+#ifndef ZEROVOX_AMD_H
+#define ZEROVOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zv_model zv_model;
+
+typedef enum
+{
+    ZV_OK = 0,
+    ZV_ERR_IO = 1,             /* file cannot be opened / read                          */
+    ZV_ERR_FORMAT = 2,         /* not a GGUF v3 file, bad KV type, truncated            */
+    ZV_ERR_MISSING = 3,        /* required KV key or tensor not found                   */
+    ZV_ERR_SHAPE = 4,          /* tensor shape / dtype does not match the contract      */
+    ZV_ERR_ARG = 5,            /* bad argument (null pointer, id out of range, T = 0 …) */
+    ZV_ERR_DEVICE = 6,         /* HIP runtime error, no gfx950 device, kernel failure   */
+    ZV_ERR_OOM = 7
+} zv_status;
+
+/* the reference's zerovox_hparams (src/zerovox.h:39-58) + the derived vocoder geometry */
+typedef struct
+{
+    uint32_t max_seq_len;
+    uint32_t emb_dim;
+    uint32_t punct_emb_dim;
+    uint32_t decoder_n_head;
+    uint32_t conv_filter_size;
+    uint32_t conv_kernel_size[2];
+    uint32_t encoder_layer;
+    uint32_t encoder_head;
+    uint32_t encoder_vp_filter_size;
+    uint32_t encoder_vp_kernel_size;
+    uint32_t encoder_ve_n_bins;
+    uint32_t audio_sampling_rate;
+    uint32_t audio_num_mels;
+    uint32_t audio_hop_size;
+    /* inferred from tensor shapes (the reference hard-codes these, src/zerovox.cpp:127-138) */
+    uint32_t voc_channels;
+    uint32_t voc_num_upsamples;
+    uint32_t voc_upsample_scales[8];
+    uint32_t voc_num_resblocks;
+    uint32_t voc_resblock_kernels[8];
+} zv_hparams;
+
+const char *zv_last_error(void);                 /* thread-local message of the last failure */
+const char *zv_version(void);
+
+/* ---- model life cycle ------------------------------------------------------------------- */
+zv_status zv_model_load(const char *gguf_path, int device, zv_model **out);
+void      zv_model_free(zv_model *m);
+zv_status zv_model_get_hparams(const zv_model *m, zv_hparams *out);
+/* size the activation arena up-front for the largest (N, T) that will be used (optional:
+ * the arena also grows on demand, outside any timed / captured region) */
+zv_status zv_model_reserve(zv_model *m, uint32_t max_phonemes, uint32_t max_frames);
+
+/* ---- the hot path: host buffers in / out, synchronous (same protocol as the reference) ---- */
+/* ids[n], puncts[n] i32; style[E] f32; hidden[T*E] f32 frame-major, zero-padded tail; returns the
+ * regulator's frame count in *n_frames (may be NULL).  Optional taps (NULL to skip): logdur[n],
+ * pitch_bucket[n], energy_bucket[n], features[n*E] — the pre-regulator values parity tests need. */
+zv_status zv_encode(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
+                    uint32_t n, uint32_t T, float *hidden, uint32_t *n_frames);
+zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
+                         uint32_t n, uint32_t T, float *hidden, uint32_t *n_frames, float *features,
+                         float *logdur, float *pitch, float *energy, int32_t *pitch_bucket,
+                         int32_t *energy_bucket);
+/* hidden[T*E], style[E] -> mel[T*num_mels] frame-major */
+zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32_t T, float *mel);
+/* mel[T*num_mels] -> wav[T*hop_size] */
+zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav);
+/* encoder -> decoder -> vocoder with every intermediate kept in HBM; wav[T*hop_size] */
+zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
+                        uint32_t n, uint32_t T, float *wav, uint32_t *n_frames);
+
+/* ---- device-resident variants (inputs already in HBM; enqueue on the model's stream) ------- */
+void     *zv_device_alloc(zv_model *m, size_t bytes);
+void      zv_device_free(zv_model *m, void *p);
+zv_status zv_memcpy_h2d(zv_model *m, void *dst, const void *src, size_t bytes);
+zv_status zv_memcpy_d2h(zv_model *m, void *dst, const void *src, size_t bytes);
+zv_status zv_vocode_device(zv_model *m, const float *d_mel, uint32_t T, float *d_wav);
+zv_status zv_decode_device(zv_model *m, const float *d_hidden, const float *d_style, uint32_t T, float *d_mel);
+zv_status zv_synchronize(zv_model *m);
+/* capture the vocoder schedule for a given T into a hipGraph and replay it on later calls with the
+ * same (T, d_mel, d_wav); 0 turns graph replay off */
+zv_status zv_set_graph_mode(zv_model *m, int on);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* per-kernel-family timing measured with HIP events on the model's stream (eager launches) */
+typedef struct
+{
+    char     name[48];
+    uint32_t launches;
+    double   total_ms;
+    double   algo_bytes;       /* algorithmic bytes moved by those launches */
+    double   algo_flops;
+} zv_kernel_stat;
+zv_status zv_profile_begin(zv_model *m);
+/* stops profiling, copies up to cap entries, returns the entry count in *n */
+zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint32_t *n);
+
+/* ---- "next" row f-2: WAV writer (PCM16 mono, 44-byte RIFF header) --------------------------- */
+zv_status zv_write_wav(const char *path, const float *wav, size_t n_samples, uint32_t sampling_rate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,212 @@
+"""ctypes binding of libzerovox_amd.so (the C-ABI of include/zerovox_amd.h).
+
+Used by the parity tests, bench.py and smoke(): the same entry points a C/C++ host would call.
+There is NO CPU fallback: if the library is missing or no gfx950 device is present, loading fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzerovox_amd.so")
+
+# every symbol include/zerovox_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
+    "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_device_alloc", "zv_device_free",
+    "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
+    "zv_profile_begin", "zv_profile_end", "zv_write_wav",
+]
+
+
+class HParams(C.Structure):
+    _fields_ = [("max_seq_len", C.c_uint32), ("emb_dim", C.c_uint32), ("punct_emb_dim", C.c_uint32),
+                ("decoder_n_head", C.c_uint32), ("conv_filter_size", C.c_uint32), ("conv_kernel_size", C.c_uint32 * 2),
+                ("encoder_layer", C.c_uint32), ("encoder_head", C.c_uint32), ("encoder_vp_filter_size", C.c_uint32),
+                ("encoder_vp_kernel_size", C.c_uint32), ("encoder_ve_n_bins", C.c_uint32),
+                ("audio_sampling_rate", C.c_uint32), ("audio_num_mels", C.c_uint32), ("audio_hop_size", C.c_uint32),
+                ("voc_channels", C.c_uint32), ("voc_num_upsamples", C.c_uint32), ("voc_upsample_scales", C.c_uint32 * 8),
+                ("voc_num_resblocks", C.c_uint32), ("voc_resblock_kernels", C.c_uint32 * 8)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double),
+                ("algo_bytes", C.c_double), ("algo_flops", C.c_double)]
+
+
+class ZvError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"zv_status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ZvError(-1, f"{p} not found: build it with `make -C zerovox.cpp_amd/csrc` (no CPU fallback exists)")
+    lib = C.CDLL(p)
+    vp, u32, i32p, fp = C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p
+    lib.zv_last_error.restype = C.c_char_p
+    lib.zv_version.restype = C.c_char_p
+    lib.zv_model_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.zv_model_free.argtypes = [vp]
+    lib.zv_model_free.restype = None
+    lib.zv_model_get_hparams.argtypes = [vp, C.POINTER(HParams)]
+    lib.zv_model_reserve.argtypes = [vp, u32, u32]
+    lib.zv_encode.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
+    lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
+    lib.zv_decode.argtypes = [vp, fp, fp, u32, fp]
+    lib.zv_vocode.argtypes = [vp, fp, u32, fp]
+    lib.zv_synthesize.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
+    lib.zv_device_alloc.argtypes = [vp, C.c_size_t]
+    lib.zv_device_alloc.restype = vp
+    lib.zv_device_free.argtypes = [vp, vp]
+    lib.zv_device_free.restype = None
+    lib.zv_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.zv_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.zv_vocode_device.argtypes = [vp, vp, u32, vp]
+    lib.zv_decode_device.argtypes = [vp, vp, vp, u32, vp]
+    lib.zv_synchronize.argtypes = [vp]
+    lib.zv_set_graph_mode.argtypes = [vp, C.c_int]
+    lib.zv_profile_begin.argtypes = [vp]
+    lib.zv_profile_end.argtypes = [vp, C.POINTER(KernelStat), u32, C.POINTER(u32)]
+    lib.zv_write_wav.argtypes = [C.c_char_p, fp, C.c_size_t, u32]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Model:
+    """One loaded checkpoint on one MI355X (zv_model)."""
+
+    def __init__(self, gguf_path: str, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.zv_model_load(gguf_path.encode(), device, C.byref(h))
+        if st != 0:
+            raise ZvError(st, self.lib.zv_last_error().decode())
+        self.h = h
+        hp = HParams()
+        self._chk(self.lib.zv_model_get_hparams(self.h, C.byref(hp)))
+        self.hp = hp
+        self.E = hp.emb_dim + hp.punct_emb_dim
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zv_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st != 0:
+            raise ZvError(st, self.lib.zv_last_error().decode())
+
+    # ---- host-buffer API (same call protocol as the reference's eval methods) ----
+    def vocode(self, mel: np.ndarray) -> np.ndarray:
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        T = mel.shape[0]
+        wav = np.empty(T * self.hp.audio_hop_size, np.float32)
+        self._chk(self.lib.zv_vocode(self.h, _ptr(mel), T, _ptr(wav)))
+        return wav
+
+    def decode(self, hidden: np.ndarray, style: np.ndarray) -> np.ndarray:
+        hidden = np.ascontiguousarray(hidden, dtype=np.float32)
+        style = np.ascontiguousarray(style, dtype=np.float32)
+        T = hidden.shape[0]
+        mel = np.empty((T, self.hp.audio_num_mels), np.float32)
+        self._chk(self.lib.zv_decode(self.h, _ptr(hidden), _ptr(style), T, _ptr(mel)))
+        return mel
+
+    def encode(self, ids, puncts, style, T: int) -> dict:
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        puncts = np.ascontiguousarray(puncts, dtype=np.int32)
+        style = np.ascontiguousarray(style, dtype=np.float32)
+        N, E = len(ids), self.E
+        out = dict(hidden=np.empty((T, E), np.float32), features=np.empty((N, E), np.float32),
+                   logdur=np.empty(N, np.float32), pitch=np.empty(N, np.float32), energy=np.empty(N, np.float32),
+                   pitch_bucket=np.empty(N, np.int32), energy_bucket=np.empty(N, np.int32))
+        nf = C.c_uint32(0)
+        self._chk(self.lib.zv_encode_taps(self.h, _ptr(ids), _ptr(puncts), _ptr(style), N, T, _ptr(out["hidden"]),
+                                          C.byref(nf), _ptr(out["features"]), _ptr(out["logdur"]), _ptr(out["pitch"]),
+                                          _ptr(out["energy"]), _ptr(out["pitch_bucket"]), _ptr(out["energy_bucket"])))
+        out["n_frames"] = int(nf.value)
+        return out
+
+    def synthesize(self, ids, puncts, style, T: int):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        puncts = np.ascontiguousarray(puncts, dtype=np.int32)
+        style = np.ascontiguousarray(style, dtype=np.float32)
+        wav = np.empty(T * self.hp.audio_hop_size, np.float32)
+        nf = C.c_uint32(0)
+        self._chk(self.lib.zv_synthesize(self.h, _ptr(ids), _ptr(puncts), _ptr(style), len(ids), T, _ptr(wav), C.byref(nf)))
+        return wav, int(nf.value)
+
+    # ---- device-resident API ----
+    def device_alloc(self, nbytes: int) -> int:
+        p = self.lib.zv_device_alloc(self.h, nbytes)
+        if not p:
+            raise ZvError(7, "zv_device_alloc failed")
+        return p
+
+    def device_free(self, p: int):
+        self.lib.zv_device_free(self.h, p)
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.zv_memcpy_h2d(self.h, dst, _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, src: int):
+        self._chk(self.lib.zv_memcpy_d2h(self.h, _ptr(arr), src, arr.nbytes))
+
+    def vocode_device(self, d_mel: int, T: int, d_wav: int):
+        self._chk(self.lib.zv_vocode_device(self.h, d_mel, T, d_wav))
+
+    def decode_device(self, d_hidden: int, d_style: int, T: int, d_mel: int):
+        self._chk(self.lib.zv_decode_device(self.h, d_hidden, d_style, T, d_mel))
+
+    def synchronize(self):
+        self._chk(self.lib.zv_synchronize(self.h))
+
+    def set_graph_mode(self, on: bool):
+        self._chk(self.lib.zv_set_graph_mode(self.h, int(on)))
+
+    def reserve(self, max_phonemes: int, max_frames: int):
+        self._chk(self.lib.zv_model_reserve(self.h, max_phonemes, max_frames))
+
+    def profile_begin(self):
+        self._chk(self.lib.zv_profile_begin(self.h))
+
+    def profile_end(self) -> list:
+        cap = 64
+        arr = (KernelStat * cap)()
+        n = C.c_uint32(0)
+        self._chk(self.lib.zv_profile_end(self.h, arr, cap, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                     algo_bytes=arr[i].algo_bytes, algo_flops=arr[i].algo_flops) for i in range(min(cap, n.value))]
+
+
+def write_wav(path: str, wav: np.ndarray, sampling_rate: int):
+    lib = load_library()
+    wav = np.ascontiguousarray(wav, dtype=np.float32)
+    st = lib.zv_write_wav(path.encode(), _ptr(wav), wav.size, sampling_rate)
+    if st != 0:
+        raise ZvError(st, lib.zv_last_error().decode())

@@ -1,0 +1,376 @@
+// capi.cpp — the extern "C" boundary declared in include/zerovox_amd.h.
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "common.h"
+#include "model.h"
+
+using zv::Model;
+
+struct zv_model
+{
+    Model *m;
+};
+
+static thread_local std::string g_last_error;
+
+template <typename F> static zv_status guarded(F &&f)
+{
+    try
+    {
+        f();
+        return ZV_OK;
+    }
+    catch (const zv::Error &e)
+    {
+        g_last_error = e.what();
+        return e.status;
+    }
+    catch (const std::bad_alloc &)
+    {
+        g_last_error = "out of host memory";
+        return ZV_ERR_OOM;
+    }
+    catch (const std::exception &e)
+    {
+        g_last_error = e.what();
+        return ZV_ERR_DEVICE;
+    }
+}
+
+#define ZV_NEED(cond, what) \
+    if (!(cond)) zv::fail(ZV_ERR_ARG, "%s: %s", __func__, what)
+
+extern "C" {
+
+const char *zv_last_error(void) { return g_last_error.c_str(); }
+const char *zv_version(void) { return "zerovox.cpp_amd 0.1 (gfx950)"; }
+
+zv_status zv_model_load(const char *gguf_path, int device, zv_model **out)
+{
+    return guarded([&] {
+        ZV_NEED(gguf_path && out, "null argument");
+        *out = nullptr;
+        Model *m = new Model(gguf_path, device);
+        *out = new zv_model{m};
+    });
+}
+
+void zv_model_free(zv_model *m)
+{
+    if (!m) return;
+    delete m->m;
+    delete m;
+}
+
+zv_status zv_model_get_hparams(const zv_model *m, zv_hparams *out)
+{
+    return guarded([&] {
+        ZV_NEED(m && out, "null argument");
+        *out = m->m->hp;
+    });
+}
+
+zv_status zv_model_reserve(zv_model *m, uint32_t max_phonemes, uint32_t max_frames)
+{
+    return guarded([&] {
+        ZV_NEED(m, "null model");
+        ZV_HIP(hipSetDevice(m->m->device));
+        m->m->reserve(max_phonemes, max_frames);
+    });
+}
+
+// ---- host-buffer entry points -------------------------------------------------------------------
+
+static void check_ids(const Model &M, const int32_t *ids, const int32_t *puncts, uint32_t n)
+{
+    // the reference aborts inside ggml_get_rows on a bad id (ggml-cpu.c:8456); 155 / 7 rows (src/zerovox.h:35-36)
+    for (uint32_t i = 0; i < n; i++)
+    {
+        if (ids[i] < 0 || ids[i] > 154) zv::fail(ZV_ERR_ARG, "phoneme id %d at position %u is outside [0, 154]", ids[i], i);
+        if (puncts[i] < 0 || puncts[i] > 6) zv::fail(ZV_ERR_ARG, "punctuation id %d at position %u is outside [0, 6]", puncts[i], i);
+    }
+    (void)M;
+}
+
+zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
+                         float *hidden, uint32_t *n_frames, float *features, float *logdur, float *pitch, float *energy,
+                         int32_t *pitch_bucket, int32_t *energy_bucket)
+{
+    return guarded([&] {
+        ZV_NEED(m && ids && puncts && style && hidden, "null argument");
+        ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        check_ids(M, ids, puncts, n);
+        const size_t E = M.E();
+        const size_t b_ids = (size_t)n * 4, b_sty = E * 4, b_hid = (size_t)T * E * 4;
+        char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + 1024);
+        int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
+        float *d_sty = (float *)(io + 2 * b_ids + 256 - (2 * b_ids) % 256);
+        float *d_hid = (float *)((char *)d_sty + ((b_sty + 255) & ~(size_t)255));
+        ZV_HIP(hipMemcpyAsync(d_ids, ids, b_ids, hipMemcpyHostToDevice, M.stream));
+        ZV_HIP(hipMemcpyAsync(d_pun, puncts, b_ids, hipMemcpyHostToDevice, M.stream));
+        ZV_HIP(hipMemcpyAsync(d_sty, style, b_sty, hipMemcpyHostToDevice, M.stream));
+        Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
+        ZV_HIP(hipMemcpyAsync(hidden, d_hid, b_hid, hipMemcpyDeviceToHost, M.stream));
+        int32_t nf = 0;
+        ZV_HIP(hipMemcpyAsync(&nf, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
+        if (features) ZV_HIP(hipMemcpyAsync(features, t.features, (size_t)n * E * 4, hipMemcpyDeviceToHost, M.stream));
+        if (logdur) ZV_HIP(hipMemcpyAsync(logdur, t.logdur, b_ids, hipMemcpyDeviceToHost, M.stream));
+        if (pitch) ZV_HIP(hipMemcpyAsync(pitch, t.pitch, b_ids, hipMemcpyDeviceToHost, M.stream));
+        if (energy) ZV_HIP(hipMemcpyAsync(energy, t.energy, b_ids, hipMemcpyDeviceToHost, M.stream));
+        if (pitch_bucket) ZV_HIP(hipMemcpyAsync(pitch_bucket, t.pitch_bucket, b_ids, hipMemcpyDeviceToHost, M.stream));
+        if (energy_bucket) ZV_HIP(hipMemcpyAsync(energy_bucket, t.energy_bucket, b_ids, hipMemcpyDeviceToHost, M.stream));
+        M.sync();
+        if (n_frames) *n_frames = (uint32_t)nf;
+    });
+}
+
+zv_status zv_encode(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
+                    float *hidden, uint32_t *n_frames)
+{
+    return zv_encode_taps(m, ids, puncts, style, n, T, hidden, n_frames, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32_t T, float *mel)
+{
+    return guarded([&] {
+        ZV_NEED(m && hidden && style && mel, "null argument");
+        ZV_NEED(T > 0, "T must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        const size_t E = M.E(), Mm = M.hp.audio_num_mels;
+        const size_t b_hid = (size_t)T * E * 4, b_sty = (E * 4 + 255) & ~(size_t)255, b_mel = (size_t)T * Mm * 4;
+        char *io = (char *)M.io_scratch(b_hid + b_sty + b_mel + 1024);
+        float *d_sty = (float *)io, *d_hid = (float *)(io + b_sty), *d_mel = (float *)(io + b_sty + ((b_hid + 255) & ~(size_t)255));
+        ZV_HIP(hipMemcpyAsync(d_hid, hidden, b_hid, hipMemcpyHostToDevice, M.stream));
+        ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
+        M.decode_dev(d_hid, d_sty, T, d_mel);
+        ZV_HIP(hipMemcpyAsync(mel, d_mel, b_mel, hipMemcpyDeviceToHost, M.stream));
+        M.sync();
+    });
+}
+
+zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
+{
+    return guarded([&] {
+        ZV_NEED(m && mel && wav, "null argument");
+        ZV_NEED(T > 0, "T must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        const size_t b_mel = ((size_t)T * M.hp.audio_num_mels * 4 + 255) & ~(size_t)255, b_wav = (size_t)T * M.hp.audio_hop_size * 4;
+        char *io = (char *)M.io_scratch(b_mel + b_wav);
+        float *d_mel = (float *)io, *d_wav = (float *)(io + b_mel);
+        ZV_HIP(hipMemcpyAsync(d_mel, mel, (size_t)T * M.hp.audio_num_mels * 4, hipMemcpyHostToDevice, M.stream));
+        M.vocode_dev_graph(d_mel, T, d_wav);
+        ZV_HIP(hipMemcpyAsync(wav, d_wav, b_wav, hipMemcpyDeviceToHost, M.stream));
+        M.sync();
+    });
+}
+
+zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
+                        float *wav, uint32_t *n_frames)
+{
+    return guarded([&] {
+        ZV_NEED(m && ids && puncts && style && wav, "null argument");
+        ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        check_ids(M, ids, puncts, n);
+        const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_ids = al((size_t)n * 4), b_sty = al(E * 4), b_hid = al((size_t)T * E * 4), b_mel = al((size_t)T * Mm * 4),
+                     b_wav = al((size_t)T * hop * 4);
+        M.reserve(n, T);
+        char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + b_mel + b_wav);
+        int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
+        float *d_sty = (float *)(io + 2 * b_ids), *d_hid = (float *)(io + 2 * b_ids + b_sty);
+        float *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
+        ZV_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+        ZV_HIP(hipMemcpyAsync(d_pun, puncts, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+        ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
+        Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
+        int32_t nf = 0;
+        ZV_HIP(hipMemcpyAsync(&nf, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
+        M.decode_dev(d_hid, d_sty, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
+        M.vocode_dev(d_mel, T, d_wav);
+        ZV_HIP(hipMemcpyAsync(wav, d_wav, (size_t)T * hop * 4, hipMemcpyDeviceToHost, M.stream));
+        M.sync();
+        if (n_frames) *n_frames = (uint32_t)nf;
+    });
+}
+
+// ---- device-resident entry points ---------------------------------------------------------------
+
+void *zv_device_alloc(zv_model *m, size_t bytes)
+{
+    if (!m) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(m->m->device) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess)
+    {
+        g_last_error = "hipMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void zv_device_free(zv_model *m, void *p)
+{
+    if (!m || !p) return;
+    hipSetDevice(m->m->device);
+    hipStreamSynchronize(m->m->stream);
+    hipFree(p);
+}
+
+zv_status zv_memcpy_h2d(zv_model *m, void *dst, const void *src, size_t bytes)
+{
+    return guarded([&] {
+        ZV_NEED(m && dst && src, "null argument");
+        ZV_HIP(hipSetDevice(m->m->device));
+        ZV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->m->stream));
+        m->m->sync();
+    });
+}
+
+zv_status zv_memcpy_d2h(zv_model *m, void *dst, const void *src, size_t bytes)
+{
+    return guarded([&] {
+        ZV_NEED(m && dst && src, "null argument");
+        ZV_HIP(hipSetDevice(m->m->device));
+        ZV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->m->stream));
+        m->m->sync();
+    });
+}
+
+zv_status zv_vocode_device(zv_model *m, const float *d_mel, uint32_t T, float *d_wav)
+{
+    return guarded([&] {
+        ZV_NEED(m && d_mel && d_wav, "null argument");
+        ZV_HIP(hipSetDevice(m->m->device));
+        m->m->vocode_dev_graph(d_mel, T, d_wav);
+    });
+}
+
+zv_status zv_decode_device(zv_model *m, const float *d_hidden, const float *d_style, uint32_t T, float *d_mel)
+{
+    return guarded([&] {
+        ZV_NEED(m && d_hidden && d_style && d_mel, "null argument");
+        ZV_HIP(hipSetDevice(m->m->device));
+        m->m->decode_dev(d_hidden, d_style, T, d_mel);
+    });
+}
+
+zv_status zv_synchronize(zv_model *m)
+{
+    return guarded([&] {
+        ZV_NEED(m, "null model");
+        ZV_HIP(hipSetDevice(m->m->device));
+        m->m->sync();
+    });
+}
+
+zv_status zv_set_graph_mode(zv_model *m, int on)
+{
+    return guarded([&] {
+        ZV_NEED(m, "null model");
+        m->m->graph_mode = on != 0;
+    });
+}
+
+// ---- measurement -----------------------------------------------------------------------------
+
+zv_status zv_profile_begin(zv_model *m)
+{
+    return guarded([&] {
+        ZV_NEED(m, "null model");
+        ZV_HIP(hipSetDevice(m->m->device));
+        m->m->sync();
+        m->m->prof_clear();
+        m->m->profiling = true;
+    });
+}
+
+zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint32_t *n)
+{
+    return guarded([&] {
+        ZV_NEED(m && n, "null argument");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        M.sync();
+        M.profiling = false;
+        std::map<std::string, zv_kernel_stat> agg;
+        std::vector<std::string> order;
+        for (auto &p : M.prof)
+        {
+            float ms = 0.f;
+            ZV_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+            auto it = agg.find(p.name);
+            if (it == agg.end())
+            {
+                zv_kernel_stat s;
+                memset(&s, 0, sizeof(s));
+                strncpy(s.name, p.name, sizeof(s.name) - 1);
+                it = agg.emplace(p.name, s).first;
+                order.push_back(p.name);
+            }
+            it->second.launches++;
+            it->second.total_ms += ms;
+            it->second.algo_bytes += p.bytes;
+            it->second.algo_flops += p.flops;
+        }
+        M.prof_clear();
+        uint32_t k = 0;
+        for (auto &name : order)
+        {
+            if (stats && k < cap) stats[k] = agg[name];
+            k++;
+        }
+        *n = k;
+    });
+}
+
+// ---- WAV writer (reference src/zerovox.cpp:337-391 uses libsndfile SF_FORMAT_WAV | SF_FORMAT_PCM_16) ----
+
+zv_status zv_write_wav(const char *path, const float *wav, size_t n_samples, uint32_t sampling_rate)
+{
+    return guarded([&] {
+        ZV_NEED(path && wav, "null argument");
+        FILE *f = fopen(path, "wb");
+        if (!f) zv::fail(ZV_ERR_IO, "cannot open '%s' for writing", path);
+        const uint32_t data_bytes = (uint32_t)(n_samples * 2);
+        uint8_t hdr[44];
+        auto put32 = [&](int o, uint32_t v) { for (int i = 0; i < 4; i++) hdr[o + i] = (uint8_t)(v >> (8 * i)); };
+        auto put16 = [&](int o, uint16_t v) { hdr[o] = (uint8_t)v; hdr[o + 1] = (uint8_t)(v >> 8); };
+        memcpy(hdr, "RIFF", 4);
+        put32(4, 36 + data_bytes);
+        memcpy(hdr + 8, "WAVEfmt ", 8);
+        put32(16, 16);
+        put16(20, 1);                 // PCM
+        put16(22, 1);                 // mono
+        put32(24, sampling_rate);
+        put32(28, sampling_rate * 2);
+        put16(32, 2);
+        put16(34, 16);
+        memcpy(hdr + 36, "data", 4);
+        put32(40, data_bytes);
+        bool ok = fwrite(hdr, 1, 44, f) == 44;
+        std::vector<int16_t> pcm(n_samples);
+        for (size_t i = 0; i < n_samples; i++)
+        {
+            // libsndfile float -> PCM16: scale by 0x7FFF (normalisation on), round to nearest, clip
+            float v = wav[i] * 32767.0f;
+            long q = lrintf(v);
+            if (q > 32767) q = 32767;
+            if (q < -32768) q = -32768;
+            pcm[i] = (int16_t)q;
+        }
+        ok = ok && fwrite(pcm.data(), 2, n_samples, f) == n_samples;
+        ok = (fclose(f) == 0) && ok;
+        if (!ok) zv::fail(ZV_ERR_IO, "short write to '%s'", path);
+    });
+}
+
+}  // extern "C"

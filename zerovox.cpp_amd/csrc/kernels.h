@@ -1,0 +1,117 @@
+// kernels.h — host-visible descriptors and launchers of the HIP kernels (gfx950 only).
+//
+// Activation layout in HBM ("tl" = time-major / channels-last): x[t * ld + c], c < Cp, where
+// Cp = C rounded up to 16 and the pad channels hold zeros.  This is the layout of the stage
+// boundaries themselves (hidden[t*E+e], mel[t*80+m] — reference src/fs2encoder.cpp:634,
+// src/stylettsdec.cpp:432-441), so no transposes exist anywhere in the schedule, and it makes an
+// MFMA operand fragment (8 consecutive input channels at one time step) one 16-byte LDS read.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zv
+{
+
+__host__ __device__ static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// ---- fused Conv1d ("same" length, stride 1) as implicit GEMM on v_mfma_f32_32x32x16_f16 -----------
+//
+//   out[t][oc] = epilogue( sum_{tap, ic} f16( prologue(x)[t + tap*dil - pad][ic] ) * w[tap][ic][oc] )
+//
+// which is ggml_conv_1d = im2col(F16) + mul_mat (reference ggml/src/ggml.c:3769-3786): operands f16,
+// products exact in f32, f32 accumulation.  Out-of-range taps are zeros *after* the prologue.
+
+enum ConvPrologue : int
+{
+    PRO_RAW_F16 = 0,      // x is already the f16 operand (written by an EPI f16 store)
+    PRO_ACT = 1,          // f16(lrelu(x, slope))            (slope 1 = identity, 0 = relu)
+    PRO_NORM_ACT = 2,     // f16(lrelu(((x - mean_c) * rstd_c) * g_c + b_c, slope))   InstanceNorm/AdaIN
+    PRO_MELNORM = 3,      // f16((x - a_c) / b_c)            (src/hifigan.cpp:242-243)
+    PRO_SUM3_ACT = 4      // f16(lrelu(((x0 + x1) + x2) * pscale, slope))   MRF mean (src/hifigan.cpp:300-315)
+};
+
+struct ConvJob
+{
+    // input
+    const void  *x0, *x1, *x2;
+    int          ldx;
+    int          pro;
+    float        slope, pscale;
+    const float *pa, *pb;        // per-channel: NORM g,b | MELNORM mean,scale
+    const float *pstat;          // per-channel (mean, rstd) pairs
+    // geometry
+    int          L, Cin_p, Cout_p, K, dil, pad;
+    int          ck;             // input-channel chunk staged per LDS pass (set at pack time)
+    // weights packed in MFMA-fragment order (see pack_conv_weight), bias padded to 32*ntiles
+    const void  *w;
+    const float *bias;
+    // epilogue: v = acc + bias; v += res; v *= escale; v = lrelu(v, oslope) if eact; store f32 | f16
+    const float *res;
+    int          ldres;
+    float        escale;
+    int          eact;
+    float        oslope;
+    int          out_f16;
+    void        *out;
+    int          ldo;
+};
+
+constexpr int CONV_MAX_JOBS = 4;
+struct ConvJobs
+{
+    ConvJob j[CONV_MAX_JOBS];
+};
+
+// bytes of one packed conv weight: [ntile32][chunk][tap][kc][lane 64][8 halfs]
+size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K);
+int    conv_pick_ck(int Cin_p);
+// host-side repack of a GGUF conv weight (ggml ne [K, IC, OC], f16, k fastest) into fragment order
+void   pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, int ck, uint16_t *dst);
+// all jobs of one launch share L-extent class, Cout_p and tile configuration
+hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu);
+
+// ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
+struct OutConvArgs
+{
+    const float *x0, *x1, *x2;   // MRF branches of the last stage, summed in the prologue
+    int          ldx, L, C, K;
+    float        pscale, slope;
+    const uint16_t *w;           // f16 [K][Cp]
+    float        bias;
+    float       *out;            // wav[L]
+};
+hipError_t launch_out_conv(hipStream_t s, const OutConvArgs &a);
+
+// ---- InstanceNorm statistics over time (ggml_norm semantics, ggml-cpu.c:6880-6929) ----------------
+// stat[c] = (mean, 1/sqrtf(var + eps)); sums accumulated in f64
+hipError_t launch_in_stats(hipStream_t s, const float *x, int ld, int L, int C, float eps, float *stat);
+// y[t][c] = ((x - mean) * rstd) * g[c] + b[c]
+hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int L, int C, const float *stat,
+                             const float *g, const float *b, float *y, int ldy);
+
+// ---- f32 linear layers: y[n][o] = dot(W[o][:], x[n][:]) + b[o] (ggml_mul_mat on f32 weights) --------
+// `extra` (may be null) is a second per-output addend applied after the bias: (acc + b[o]) + extra[o]
+// (AdaIN: gamma = h[:C] + 1, reference src/stylettsdec.cpp:186-189)
+hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int n, int in, const float *W, const float *b,
+                         int out, float *y, int ldy, const float *extra);
+
+// ---- encoder pieces (reference src/fs2encoder.cpp) -------------------------------------------------
+hipError_t launch_embed(hipStream_t s, const int32_t *ids, const int32_t *puncts, const float *wemb, int emb,
+                        const float *pemb, int pdim, const float *posenc, int n, float *x, int ld);
+hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const float *v, int ld, int n, int H,
+                            int dk, float inv_temp, float *o, int ldo);
+// y = LayerNorm(x + res) * w + b  over the C real channels (res may be null); channels [C, Cp) are zeroed
+hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int n, int C,
+                                int Cp, const float *w, const float *b, float eps, float *y, int ldy);
+hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int n, int C, const float *v);
+// pred[n] = dot(x[n][:], w) + b
+hipError_t launch_rowdot(hipStream_t s, const float *x, int ld, int n, int C, const float *w, const float *b, float *y);
+// bucket[n] = clamp((int)(pred*(nbins-1) + 0.5), 0, nbins-1); x[n][:] += emb[bucket[n]][:]
+hipError_t launch_bucket_embed_add(hipStream_t s, const float *pred, int n, int nbins, const float *emb, int C,
+                                   float *x, int ld, int32_t *bucket);
+// device length regulator: rounded durations -> exclusive scan -> gather, zero tail; n_frames[0] = frames
+hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int n, int C,
+                                   int T, float *hidden, int ldh, int32_t *n_frames);
+
+}  // namespace zv

@@ -1,0 +1,938 @@
+// model.cpp — loader + fixed kernel schedules (see model.h).
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace zv
+{
+
+static const char *KV_PREFIX = "zerovox-resnet-fs2-styletts.";   // reference src/zerovox.h:17-33
+
+// ---------------------------------------------------------------------------------------------------
+// weights
+
+void *Model::dev_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) fail(ZV_ERR_OOM, "hipMalloc(%zu) failed", bytes);
+    allocs_.push_back(p);
+    return p;
+}
+
+float *Model::upload_f32(const GgufTensor &t, int pad_to, float pad_value)
+{
+    if (t.type != GGML_F32) fail(ZV_ERR_SHAPE, "tensor %s: expected f32", t.name.c_str());
+    const size_t n = (size_t)t.nelements();
+    const size_t np = pad_to > 0 ? (size_t)std::max<int64_t>(pad_to, (int64_t)n) : n;
+    std::vector<float> h(np + 64, pad_value);            // 64 floats of slack: prologues read whole float4 groups
+    memcpy(h.data(), t.data, n * sizeof(float));
+    float *d = (float *)dev_alloc(h.size() * sizeof(float));
+    ZV_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+float *Model::upload_vec(const GgufFile &g, const std::string &name, int expect_n, int pad_to, float pad_value)
+{
+    const GgufTensor &t = g.get(name);
+    if (t.nelements() != expect_n) fail(ZV_ERR_SHAPE, "tensor %s: expected %d elements, found %lld", name.c_str(), expect_n, (long long)t.nelements());
+    return upload_f32(t, pad_to, pad_value);
+}
+
+// GGUF conv weight: ggml ne [K, IC, OC] f16 (k fastest), bias f32 [OC]  (SURVEY.md Appx A)
+ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin)
+{
+    const GgufTensor &w = g.get(wname);
+    if (w.type != GGML_F16) fail(ZV_ERR_SHAPE, "tensor %s: conv weights must be f16", wname.c_str());
+    ConvW c;
+    c.K = (int)w.ne[0];
+    c.Cin = (int)w.ne[1];
+    c.Cout = (int)w.ne[2];
+    if (expect_cin >= 0 && c.Cin != expect_cin) fail(ZV_ERR_SHAPE, "tensor %s: expected %d input channels, found %d", wname.c_str(), expect_cin, c.Cin);
+    if ((c.K & 1) == 0) fail(ZV_ERR_SHAPE, "tensor %s: even kernel size %d is not a 'same' conv", wname.c_str(), c.K);
+    c.Cin_p = round_up(c.Cin, 16);
+    c.Cout_p = round_up(c.Cout, 16);
+    c.ck = conv_pick_ck(c.Cin_p);
+    std::vector<uint16_t> packed(packed_conv_weight_halfs(c.Cin_p, c.Cout_p, c.K));
+    pack_conv_weight((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
+    c.w = dev_alloc(packed.size() * 2);
+    ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    if (!bname.empty())
+    {
+        const GgufTensor &b = g.get(bname);
+        if (b.type != GGML_F32 || b.nelements() != c.Cout) fail(ZV_ERR_SHAPE, "tensor %s: expected f32[%d]", bname.c_str(), c.Cout);
+        c.bias = upload_f32(b, round_up(c.Cout_p, 32), 0.f);
+    }
+    return c;
+}
+
+// ConvTranspose1d(stride s, kernel K, padding p = s/2 + s%2, output_padding s%2) as the reference defines it:
+// zero-stuff + conv with the stored, already flipped kernel (src/hifigan.cpp:22-71).  Output sample
+// t = q*s + r only sees stuffed positions off + i*s, i.e. taps k = off - r + (i - q)*s: per phase r a
+// short conv over the *un-stuffed* input.  All s phases become one ordinary conv with s*Cout_p output
+// channels (channel r*Cout_p + oc) whose channels-last output [L][s*Cout_p] IS the up-sampled
+// sequence [L*s][Cout_p] — no stuffed buffer, no s-fold wasted MACs.
+ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_cin)
+{
+    char nm[96];
+    snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.w", idx);
+    const GgufTensor &w = g.get(nm);
+    if (w.type != GGML_F16) fail(ZV_ERR_SHAPE, "tensor %s: conv weights must be f16", nm);
+    const int K = (int)w.ne[0], IC = (int)w.ne[1], OC = (int)w.ne[2];
+    if (IC != expect_cin) fail(ZV_ERR_SHAPE, "tensor %s: expected %d input channels, found %d", nm, expect_cin, IC);
+    const int s = stride;
+    const int p = s / 2 + s % 2, op = s % 2;
+    const int off = (K - 1) - p;
+    // reference output length: (L-1)*s + 1 + 2*off + op - (K-1) must equal L*s
+    if (2 * off + op + 1 - (K - 1) != s) fail(ZV_ERR_SHAPE, "tensor %s: kernel %d / stride %d do not give L*s outputs", nm, K, s);
+    // delta = i - q over all (k, r):  k = off - r + delta*s
+    int dmin = 0, dmax = 0;
+    for (int r = 0; r < s; r++)
+        for (int k = 0; k < K; k++)
+            if ((k - off + r) % s == 0)
+            {
+                const int d = (k - off + r) / s;
+                dmin = std::min(dmin, d);
+                dmax = std::max(dmax, d);
+            }
+    const int nd = std::max(-dmin, dmax);          // symmetric window so the conv stays a "same" conv
+    ConvW c;
+    c.K = 2 * nd + 1;
+    c.Cin = IC;
+    c.Cin_p = round_up(IC, 16);
+    const int OCp = round_up(OC, 16);
+    c.Cout = s * OCp;
+    c.Cout_p = s * OCp;
+    c.ck = conv_pick_ck(c.Cin_p);
+    // virtual weight in GGUF conv layout [OC'][IC][K'] (k fastest)
+    std::vector<uint16_t> v((size_t)c.Cout * IC * c.K, 0);
+    const uint16_t *src = (const uint16_t *)w.data;
+    for (int r = 0; r < s; r++)
+        for (int oc = 0; oc < OC; oc++)
+            for (int ic = 0; ic < IC; ic++)
+                for (int tp = 0; tp < c.K; tp++)
+                {
+                    const int k = off - r + (tp - nd) * s;
+                    if (k >= 0 && k < K) v[((size_t)(r * OCp + oc) * IC + ic) * c.K + tp] = src[((size_t)oc * IC + ic) * K + k];
+                }
+    std::vector<uint16_t> packed(packed_conv_weight_halfs(c.Cin_p, c.Cout_p, c.K));
+    pack_conv_weight(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
+    c.w = dev_alloc(packed.size() * 2);
+    ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.b", idx);
+    const GgufTensor &b = g.get(nm);
+    if (b.type != GGML_F32 || b.nelements() != OC) fail(ZV_ERR_SHAPE, "tensor %s: expected f32[%d]", nm, OC);
+    std::vector<float> hb(round_up(c.Cout_p, 32) + 64, 0.f);
+    for (int r = 0; r < s; r++) memcpy(hb.data() + (size_t)r * OCp, b.data, (size_t)OC * 4);
+    c.bias = (float *)dev_alloc(hb.size() * 4);
+    ZV_HIP(hipMemcpy(c.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    return c;
+}
+
+Model::Model(const std::string &path, int dev) : device(dev)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(ZV_ERR_DEVICE, "no HIP device available");
+    if (dev < 0 || dev >= ndev) fail(ZV_ERR_ARG, "device %d out of range (%d devices)", dev, ndev);
+    ZV_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    ZV_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) fail(ZV_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+    n_cu = prop.multiProcessorCount;
+    ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    GgufFile g;
+    g.open(path);
+    auto kv = [&](const char *k) { return g.get_u32(std::string(KV_PREFIX) + k); };
+    // all 15 keys are required, as in the reference (src/zerovox.cpp:39-56)
+    hp.max_seq_len = kv("max_seq_len");
+    hp.emb_dim = kv("emb_dim");
+    hp.punct_emb_dim = kv("punct_emb_dim");
+    hp.decoder_n_head = kv("decoder.n_head");
+    hp.conv_filter_size = kv("decoder.conv_filter_size");
+    hp.conv_kernel_size[0] = kv("decoder.conv_kernel_size.0");
+    hp.conv_kernel_size[1] = kv("decoder.conv_kernel_size.1");
+    hp.encoder_layer = kv("encoder.layer");
+    hp.encoder_head = kv("encoder.head");
+    hp.encoder_vp_filter_size = kv("encoder.vp_filter_size");
+    hp.encoder_vp_kernel_size = kv("encoder.vp_kernel_size");
+    hp.encoder_ve_n_bins = kv("encoder.ve_n_bins");
+    hp.audio_sampling_rate = kv("audio.sampling_rate");
+    hp.audio_num_mels = kv("audio.num_mels");
+    hp.audio_hop_size = kv("audio.hop_size");
+
+    const int Ed = (int)E();
+    if (Ed % 16) fail(ZV_ERR_SHAPE, "emb_dim + punct_emb_dim = %d must be a multiple of 16", Ed);
+    if (hp.audio_num_mels % 16) fail(ZV_ERR_SHAPE, "num_mels = %u must be a multiple of 16", hp.audio_num_mels);
+    if (hp.encoder_head == 0 || Ed % hp.encoder_head) fail(ZV_ERR_SHAPE, "encoder.head = %u does not divide %d", hp.encoder_head, Ed);
+    if (hp.encoder_vp_kernel_size != 3) fail(ZV_ERR_SHAPE, "vp_kernel_size = %u: the reference pads the second predictor conv with a literal 1 (src/fs2encoder.cpp:417), only 3 is a 'same' conv", hp.encoder_vp_kernel_size);
+    char nm[128], nb[128];
+
+    // ---------------- vocoder (src/hifigan.cpp:208-218; geometry from tensor shapes) ----------------
+    const int M = (int)hp.audio_num_mels;
+    voc_.mean = upload_vec(g, "hifigan.mean", M);
+    voc_.scale = upload_vec(g, "hifigan.scale", M, 0, 1.f);
+    voc_.in_conv = load_conv(g, "_meldec.input_conv.w", "_meldec.input_conv.b", M);
+    int C = voc_.in_conv.Cout;
+    hp.voc_channels = C;
+    int n_up = 0;
+    while (n_up < 8)
+    {
+        snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.w", n_up);
+        if (!g.find(nm)) break;
+        n_up++;
+    }
+    if (n_up == 0) fail(ZV_ERR_MISSING, "tensor '_meldec.upsamples.0.1.w' not found");
+    // the stride is not stored in the file: the reference hard-codes {5,5,4,3} (src/zerovox.cpp:129);
+    // every HiFi-GAN config has kernel = 2 * stride, which is what we derive and check against hop_size.
+    int hop = 1;
+    voc_.n_up = n_up;
+    hp.voc_num_upsamples = n_up;
+    int n_blocks = 0;
+    while (true)
+    {
+        snprintf(nm, sizeof(nm), "_meldec.blocks.%d.convs1.0.1.w", n_blocks);
+        if (!g.find(nm)) break;
+        n_blocks++;
+    }
+    if (n_blocks == 0 || n_blocks % n_up) fail(ZV_ERR_SHAPE, "%d residual blocks do not divide over %d upsample stages", n_blocks, n_up);
+    voc_.n_rb = n_blocks / n_up;
+    if (voc_.n_rb != 3) fail(ZV_ERR_SHAPE, "num_resblocks = %d: the schedule (like the reference caller) is built for 3", voc_.n_rb);
+    hp.voc_num_resblocks = voc_.n_rb;
+    for (int i = 0; i < n_up; i++)
+    {
+        snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.w", i);
+        const int K = (int)g.get(nm).ne[0];
+        if (K % 2) fail(ZV_ERR_SHAPE, "tensor %s: odd transposed-conv kernel %d", nm, K);
+        const int s = K / 2;
+        voc_.scales[i] = s;
+        hp.voc_upsample_scales[i] = s;
+        hop *= s;
+        voc_.ups[i] = load_upsample(g, i, s, C);
+        C = (int)g.get(nm).ne[2];
+        for (int j = 0; j < voc_.n_rb; j++)
+            for (int d = 0; d < voc_.n_dil; d++)
+            {
+                ResPair rp;
+                const int n = i * voc_.n_rb + j;
+                snprintf(nm, sizeof(nm), "_meldec.blocks.%d.convs1.%d.1.w", n, d);
+                snprintf(nb, sizeof(nb), "_meldec.blocks.%d.convs1.%d.1.b", n, d);
+                rp.c1 = load_conv(g, nm, nb, C);
+                snprintf(nm, sizeof(nm), "_meldec.blocks.%d.convs2.%d.1.w", n, d);
+                snprintf(nb, sizeof(nb), "_meldec.blocks.%d.convs2.%d.1.b", n, d);
+                rp.c2 = load_conv(g, nm, nb, C);
+                if (rp.c1.Cout != C || rp.c2.Cout != C) fail(ZV_ERR_SHAPE, "residual block %d: channel mismatch", n);
+                if (i == 0 && d == 0) hp.voc_resblock_kernels[j] = rp.c1.K;
+                voc_.pairs.push_back(rp);
+            }
+    }
+    if ((uint32_t)hop != hp.audio_hop_size) fail(ZV_ERR_SHAPE, "product of upsample scales %d != audio.hop_size %u", hop, hp.audio_hop_size);
+    {
+        const GgufTensor &w = g.get("_meldec.output_conv.1.w");
+        const GgufTensor &b = g.get("_meldec.output_conv.1.b");
+        if (w.type != GGML_F16 || w.ne[1] != C || w.ne[2] != 1) fail(ZV_ERR_SHAPE, "_meldec.output_conv.1.w: expected f16 [K,%d,1]", C);
+        voc_.out_K = (int)w.ne[0];
+        voc_.out_C = C;
+        const int Cp = round_up(C, 16);
+        std::vector<uint16_t> h((size_t)voc_.out_K * Cp, 0);
+        const uint16_t *src = (const uint16_t *)w.data;
+        for (int ic = 0; ic < C; ic++)
+            for (int k = 0; k < voc_.out_K; k++) h[(size_t)k * Cp + ic] = src[(size_t)ic * voc_.out_K + k];
+        voc_.out_w = (uint16_t *)dev_alloc(h.size() * 2);
+        ZV_HIP(hipMemcpy(voc_.out_w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        voc_.out_b = ((const float *)b.data)[0];
+    }
+
+    // ---------------- decoder (src/stylettsdec.cpp:33-66,163-168,220-239,334-340) ----------------
+    {
+        dec_.M = M;
+        const GgufTensor &a0 = g.get("_mel_decoder.asr_res.0.w");
+        dec_.R = (int)a0.ne[2];
+        const int R = dec_.R, B = 2 * Ed, CAT = B + R;
+        if (R % 16) fail(ZV_ERR_SHAPE, "residual_dim = %d must be a multiple of 16", R);
+        const int edims[2][2] = {{Ed, B}, {B, B}};
+        for (int i = 0; i < 2; i++)
+        {
+            DecBlk &b = dec_.enc[i];
+            b.cin = edims[i][0];
+            b.cout = edims[i][1];
+            b.learned_sc = b.cin != b.cout;
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv1.w", i);
+            snprintf(nb, sizeof(nb), "_mel_decoder.encode.%d.conv1.b", i);
+            b.conv1 = load_conv(g, nm, nb, b.cin);
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv2.w", i);
+            snprintf(nb, sizeof(nb), "_mel_decoder.encode.%d.conv2.b", i);
+            b.conv2 = load_conv(g, nm, nb, b.cin);
+            if (b.conv1.Cout != b.cin || b.conv2.Cout != b.cout) fail(ZV_ERR_SHAPE, "_mel_decoder.encode.%d: channel mismatch", i);
+            if (b.learned_sc)
+            {
+                snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv1x1.w", i);
+                b.sc = load_conv(g, nm, "", b.cin);
+            }
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm1.w", i); b.n1w = upload_vec(g, nm, b.cin);
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm1.b", i); b.n1b = upload_vec(g, nm, b.cin);
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm2.w", i); b.n2w = upload_vec(g, nm, b.cin);
+            snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm2.b", i); b.n2b = upload_vec(g, nm, b.cin);
+        }
+        dec_.asr0 = load_conv(g, "_mel_decoder.asr_res.0.w", "_mel_decoder.asr_res.0.b", Ed);
+        dec_.asr1w = upload_vec(g, "_mel_decoder.asr_res.1.w", R);
+        dec_.asr1b = upload_vec(g, "_mel_decoder.asr_res.1.b", R);
+        const int ddims[5][2] = {{CAT, B}, {CAT, B}, {CAT, Ed}, {Ed, Ed}, {Ed, Ed}};
+        // all ten AdaIN fc layers (Linear(E -> 2C)) concatenated into one GEMV; `extra` carries the +1 of gamma
+        int fc_out = 0;
+        for (int i = 0; i < 5; i++) fc_out += 2 * ddims[i][0] + 2 * ddims[i][1];
+        std::vector<float> W((size_t)fc_out * Ed), Bv(fc_out + 64, 0.f), Ex(fc_out + 64, 0.f);
+        int o = 0;
+        for (int i = 0; i < 5; i++)
+        {
+            DecBlk &b = dec_.dec[i];
+            b.cin = ddims[i][0];
+            b.cout = ddims[i][1];
+            b.learned_sc = b.cin != b.cout;
+            snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv1.w", i);
+            snprintf(nb, sizeof(nb), "_mel_decoder.decode.%d.conv1.b", i);
+            b.conv1 = load_conv(g, nm, nb, b.cin);
+            snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv2.w", i);
+            snprintf(nb, sizeof(nb), "_mel_decoder.decode.%d.conv2.b", i);
+            b.conv2 = load_conv(g, nm, nb, b.cout);
+            if (b.conv1.Cout != b.cout || b.conv2.Cout != b.cout) fail(ZV_ERR_SHAPE, "_mel_decoder.decode.%d: channel mismatch", i);
+            if (b.learned_sc)
+            {
+                snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv1x1.w", i);
+                b.sc = load_conv(g, nm, "", b.cin);
+            }
+            for (int k = 1; k <= 2; k++)
+            {
+                const int Cn = (k == 1) ? b.cin : b.cout;
+                snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.norm%d.fc.w", i, k);
+                snprintf(nb, sizeof(nb), "_mel_decoder.decode.%d.norm%d.fc.b", i, k);
+                const GgufTensor &fw = g.get(nm), &fb = g.get(nb);
+                if (fw.type != GGML_F32 || fw.ne[0] != Ed || fw.ne[1] != 2 * Cn) fail(ZV_ERR_SHAPE, "tensor %s: expected f32 [%d, %d]", nm, Ed, 2 * Cn);
+                if (fb.type != GGML_F32 || fb.nelements() != 2 * Cn) fail(ZV_ERR_SHAPE, "tensor %s: expected f32 [%d]", nb, 2 * Cn);
+                memcpy(W.data() + (size_t)o * Ed, fw.data, (size_t)2 * Cn * Ed * 4);
+                memcpy(Bv.data() + o, fb.data, (size_t)2 * Cn * 4);
+                for (int c = 0; c < Cn; c++) Ex[o + c] = 1.0f;
+                (k == 1 ? b.g1 : b.g2) = o;
+                o += 2 * Cn;
+            }
+        }
+        dec_.fc_out = fc_out;
+        dec_.fcW = (float *)dev_alloc(W.size() * 4);
+        dec_.fcB = (float *)dev_alloc(Bv.size() * 4);
+        dec_.fcExtra = (float *)dev_alloc(Ex.size() * 4);
+        ZV_HIP(hipMemcpy(dec_.fcW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+        ZV_HIP(hipMemcpy(dec_.fcB, Bv.data(), Bv.size() * 4, hipMemcpyHostToDevice));
+        ZV_HIP(hipMemcpy(dec_.fcExtra, Ex.data(), Ex.size() * 4, hipMemcpyHostToDevice));
+        dec_.to_out = load_conv(g, "_mel_decoder.to_out.0.w", "_mel_decoder.to_out.0.b", Ed);
+        if (dec_.to_out.Cout != M) fail(ZV_ERR_SHAPE, "_mel_decoder.to_out.0.w: expected %d output channels", M);
+    }
+
+    // ---------------- encoder (src/fs2encoder.cpp:29-62,152-171,256-261,344-382,504-505) ----------------
+    {
+        const GgufTensor &we = g.get("_pe._enc.src_word_emb.w");
+        const GgufTensor &pe = g.get("_pe._enc.punct_embed.w");
+        const GgufTensor &st = g.get("sinusoid_encoding_table");
+        if (we.ne[0] != hp.emb_dim || pe.ne[0] != hp.punct_emb_dim || st.ne[0] != Ed) fail(ZV_ERR_SHAPE, "embedding / position tables do not match emb_dim/punct_emb_dim");
+        enc_.wemb = upload_f32(we);
+        enc_.pemb = upload_f32(pe);
+        enc_.posenc = upload_f32(st);
+        enc_.posenc_rows = (int)st.ne[1];
+        enc_.layers.resize(hp.encoder_layer);
+        for (uint32_t l = 0; l < hp.encoder_layer; l++)
+        {
+            EncLayer &L = enc_.layers[l];
+            std::vector<float> W((size_t)3 * Ed * Ed), Bv(3 * Ed + 64, 0.f);
+            const char *names[3] = {"w_qs", "w_ks", "w_vs"};
+            for (int i = 0; i < 3; i++)
+            {
+                snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.slf_attn.%s.w", l, names[i]);
+                snprintf(nb, sizeof(nb), "_pe._enc.laystk.%u.slf_attn.%s.b", l, names[i]);
+                const GgufTensor &w = g.get(nm), &b = g.get(nb);
+                if (w.type != GGML_F32 || w.ne[0] != Ed || w.ne[1] != Ed || b.nelements() != Ed) fail(ZV_ERR_SHAPE, "tensor %s: expected f32 [%d, %d]", nm, Ed, Ed);
+                memcpy(W.data() + (size_t)i * Ed * Ed, w.data, (size_t)Ed * Ed * 4);
+                memcpy(Bv.data() + (size_t)i * Ed, b.data, (size_t)Ed * 4);
+            }
+            L.qkvW = (float *)dev_alloc(W.size() * 4);
+            L.qkvB = (float *)dev_alloc(Bv.size() * 4);
+            ZV_HIP(hipMemcpy(L.qkvW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+            ZV_HIP(hipMemcpy(L.qkvB, Bv.data(), Bv.size() * 4, hipMemcpyHostToDevice));
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.slf_attn.fc.w", l);
+            const GgufTensor &fw = g.get(nm);
+            if (fw.type != GGML_F32 || fw.ne[0] != Ed || fw.ne[1] != Ed) fail(ZV_ERR_SHAPE, "tensor %s: expected f32 [%d, %d]", nm, Ed, Ed);
+            L.fcW = upload_f32(fw);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.slf_attn.fc.b", l); L.fcB = upload_vec(g, nm, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.slf_attn.layer_norm.w", l); L.ln1w = upload_vec(g, nm, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.slf_attn.layer_norm.b", l); L.ln1b = upload_vec(g, nm, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.pos_ffn.layer_norm.w", l); L.ln2w = upload_vec(g, nm, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.pos_ffn.layer_norm.b", l); L.ln2b = upload_vec(g, nm, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.pos_ffn.w_1.w", l);
+            snprintf(nb, sizeof(nb), "_pe._enc.laystk.%u.pos_ffn.w_1.b", l);
+            L.w1 = load_conv(g, nm, nb, Ed);
+            snprintf(nm, sizeof(nm), "_pe._enc.laystk.%u.pos_ffn.w_2.w", l);
+            snprintf(nb, sizeof(nb), "_pe._enc.laystk.%u.pos_ffn.w_2.b", l);
+            L.w2 = load_conv(g, nm, nb, L.w1.Cout);
+            if (L.w2.Cout != Ed) fail(ZV_ERR_SHAPE, "pos_ffn.w_2 must map back to %d channels", Ed);
+            if (L.w1.K != (int)hp.conv_kernel_size[0] || L.w2.K != (int)hp.conv_kernel_size[1]) fail(ZV_ERR_SHAPE, "pos_ffn kernel sizes do not match the KV keys");
+        }
+        auto load_vp = [&](VarPred &v, const char *prefix) {
+            snprintf(nm, sizeof(nm), "%s.conv_layer.conv1d_1.conv.w", prefix);
+            snprintf(nb, sizeof(nb), "%s.conv_layer.conv1d_1.conv.b", prefix);
+            v.c1 = load_conv(g, nm, nb, Ed);
+            v.V = v.c1.Cout;
+            snprintf(nm, sizeof(nm), "%s.conv_layer.conv1d_2.conv.w", prefix);
+            snprintf(nb, sizeof(nb), "%s.conv_layer.conv1d_2.conv.b", prefix);
+            v.c2 = load_conv(g, nm, nb, v.V);
+            if (v.c1.K != 3 || v.c2.K != 3 || v.c2.Cout != v.V) fail(ZV_ERR_SHAPE, "%s: predictor convs must be k3, %d -> %d", prefix, v.V, v.V);
+            snprintf(nm, sizeof(nm), "%s.conv_layer.layer_norm_1.w", prefix); v.l1w = upload_vec(g, nm, v.V);
+            snprintf(nm, sizeof(nm), "%s.conv_layer.layer_norm_1.b", prefix); v.l1b = upload_vec(g, nm, v.V);
+            snprintf(nm, sizeof(nm), "%s.conv_layer.layer_norm_2.w", prefix); v.l2w = upload_vec(g, nm, v.V);
+            snprintf(nm, sizeof(nm), "%s.conv_layer.layer_norm_2.b", prefix); v.l2b = upload_vec(g, nm, v.V);
+            snprintf(nm, sizeof(nm), "%s.linear_layer.w", prefix); v.lw = upload_vec(g, nm, v.V);
+            snprintf(nm, sizeof(nm), "%s.linear_layer.b", prefix); v.lb = upload_vec(g, nm, 1);
+        };
+        load_vp(enc_.dur, "_pe._var_adapt.duration_predictor");
+        load_vp(enc_.pitch, "_pe._var_adapt.pitch_predictor");
+        load_vp(enc_.energy, "_pe._var_adapt.engy_pred");
+        const GgufTensor &pemb = g.get("_pe._var_adapt.pitch_embedding.w"), &eemb = g.get("_pe._var_adapt.energy_embedding.w");
+        if (pemb.ne[0] != Ed || pemb.ne[1] != hp.encoder_ve_n_bins || eemb.ne[0] != Ed || eemb.ne[1] != hp.encoder_ve_n_bins)
+            fail(ZV_ERR_SHAPE, "pitch/energy embedding: expected f32 [%d, %u]", Ed, hp.encoder_ve_n_bins);
+        enc_.pitch_emb = upload_f32(pemb);
+        enc_.energy_emb = upload_f32(eemb);
+    }
+    ZV_HIP(hipDeviceSynchronize());
+}
+
+Model::~Model()
+{
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    drop_graphs();
+    prof_clear();
+    for (void *p : allocs_) hipFree(p);
+    if (arena_.base) hipFree(arena_.base);
+    if (io_) hipFree(io_);
+    if (stream) hipStreamDestroy(stream);
+}
+
+void Model::sync() { ZV_HIP(hipStreamSynchronize(stream)); }
+
+void *Model::io_scratch(size_t bytes)
+{
+    if (bytes > io_cap_)
+    {
+        ZV_HIP(hipStreamSynchronize(stream));
+        if (io_) hipFree(io_);
+        io_ = nullptr;
+        io_cap_ = 0;
+        if (hipMalloc(&io_, bytes) != hipSuccess) fail(ZV_ERR_OOM, "hipMalloc(%zu) for I/O scratch failed", bytes);
+        io_cap_ = bytes;
+    }
+    return io_;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// activation arena
+
+size_t Model::arena_bytes_for(uint32_t N, uint32_t T) const
+{
+    const size_t Ed = E();
+    // vocoder: c0 + two ping-pong pools of (up + 3 y + 3 xt) sized for the widest stages
+    size_t voc = (size_t)T * round_up(hp.voc_channels, 16) * 4;
+    size_t pool[2] = {0, 0};
+    size_t L = T;
+    int C = hp.voc_channels;
+    for (uint32_t i = 0; i < hp.voc_num_upsamples; i++)
+    {
+        L *= hp.voc_upsample_scales[i];
+        C >>= 1;
+        const size_t Cp = round_up(C, 16);
+        const size_t need = L * Cp * (4 + 3 * 4 + 3 * 2) + 16 * 256;
+        pool[i & 1] = std::max(pool[i & 1], need);
+    }
+    voc += pool[0] + pool[1] + 4096;
+    // decoder: cat + a handful of [T][2E] buffers
+    const size_t CAT = 2 * Ed + dec_.R;
+    size_t dec = (size_t)T * (CAT + 4 * 2 * Ed + 2 * dec_.R) * 4 + (size_t)(dec_.fc_out + 4 * CAT) * 4 * 2 + 65536;
+    // encoder
+    const size_t Fp = round_up(hp.conv_filter_size, 16);
+    size_t enc = (size_t)N * (Ed * 8 + 3 * Ed + Fp + 1024) * 4 + (size_t)T * Ed * 4 + 65536;
+    return std::max(voc, std::max(dec, enc)) + (1 << 20);
+}
+
+void Model::arena_require(size_t bytes)
+{
+    if (bytes <= arena_.cap) return;
+    ZV_HIP(hipStreamSynchronize(stream));
+    drop_graphs();
+    if (arena_.base) hipFree(arena_.base);
+    arena_ = DeviceArena();
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) fail(ZV_ERR_OOM, "hipMalloc(%zu) for the activation arena failed", bytes);
+    ZV_HIP(hipMemset(p, 0, bytes));
+    arena_.base = (char *)p;
+    arena_.cap = bytes;
+}
+
+void Model::reserve(uint32_t max_phonemes, uint32_t max_frames)
+{
+    arena_require(arena_bytes_for(std::max(1u, max_phonemes), std::max(1u, max_frames)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch helpers
+
+void Model::prof_clear()
+{
+    for (auto &p : prof)
+    {
+        hipEventDestroy(p.e0);
+        hipEventDestroy(p.e1);
+    }
+    prof.clear();
+}
+
+void Model::tick(const char *, double, double, hipEvent_t *e0)
+{
+    *e0 = nullptr;
+    if (!profiling) return;
+    ZV_HIP(hipEventCreate(e0));
+    ZV_HIP(hipEventRecord(*e0, stream));
+}
+
+void Model::tock(hipEvent_t e0, const char *name, double bytes, double flops)
+{
+    if (!profiling) return;
+    hipEvent_t e1;
+    ZV_HIP(hipEventCreate(&e1));
+    ZV_HIP(hipEventRecord(e1, stream));
+    prof.push_back({name, e0, e1, bytes, flops});
+}
+
+#define ZV_LAUNCH(name, bytes, flops, call)          \
+    do                                               \
+    {                                                \
+        hipEvent_t _e0;                              \
+        tick(name, bytes, flops, &_e0);              \
+        ZV_HIP(call);                                \
+        tock(_e0, name, bytes, flops);               \
+    } while (0)
+
+ConvJob Model::job(const ConvW &w, int L) const
+{
+    ConvJob j;
+    memset(&j, 0, sizeof(j));
+    j.L = L;
+    j.Cin_p = w.Cin_p;
+    j.Cout_p = w.Cout_p;
+    j.K = w.K;
+    j.dil = 1;
+    j.pad = (w.K - 1) / 2;
+    j.ck = w.ck;
+    j.w = w.w;
+    j.bias = w.bias;
+    j.pro = PRO_ACT;
+    j.slope = 1.0f;
+    j.pscale = 1.0f;
+    j.escale = 1.0f;
+    j.ldx = w.Cin_p;
+    j.ldo = w.Cout_p;
+    return j;
+}
+
+void Model::conv(const ConvJob *jobs, int n, const char *name, double bytes, double flops)
+{
+    ZV_LAUNCH(name, bytes, flops, launch_conv(stream, jobs, n, n_cu));
+}
+
+// algorithmic bytes / flops of one conv layer: f32 activations in + out (+ residual),
+// f16 weights, f32 bias; 2*L*Cin*Cout*K flops
+static double conv_bytes(int L, int Cin, int Cout, int K, bool res)
+{
+    return 4.0 * L * Cin + 4.0 * L * Cout + (res ? 4.0 * L * Cout : 0.0) + 2.0 * Cin * Cout * K + 4.0 * Cout;
+}
+static double conv_flops(int L, int Cin, int Cout, int K) { return 2.0 * L * Cin * Cout * K; }
+
+// ---------------------------------------------------------------------------------------------------
+// HiFi-GAN vocoder (reference src/hifigan.cpp:187-377): fixed schedule of 2 + n_up * 7 launches
+
+void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
+{
+    if (T == 0) fail(ZV_ERR_ARG, "T must be > 0");
+    arena_require(arena_bytes_for(1, T));
+    arena_.used = 0;
+    const int M = hp.audio_num_mels;
+    int L = (int)T;
+    int C = voc_.in_conv.Cout;
+    float *c0 = arena_.take_n<float>((size_t)L * voc_.in_conv.Cout_p);
+
+    // V0: (mel - mean) / scale -> input conv k7 + bias            (src/hifigan.cpp:242-265)
+    {
+        ConvJob j = job(voc_.in_conv, L);
+        j.x0 = d_mel;
+        j.ldx = M;
+        j.pro = PRO_MELNORM;
+        j.pa = voc_.mean;
+        j.pb = voc_.scale;
+        j.out = c0;
+        conv(&j, 1, "voc_input_conv", conv_bytes(L, M, C, j.K, false), conv_flops(L, M, C, j.K));
+    }
+
+    char *pool_base[2];
+    size_t pool_sz[2] = {0, 0};
+    {
+        size_t Ls = T;
+        int Cs = C;
+        for (int i = 0; i < voc_.n_up; i++)
+        {
+            Ls *= voc_.scales[i];
+            Cs >>= 1;
+            const size_t need = Ls * round_up(Cs, 16) * (4 + 3 * 4 + 3 * 2) + 16 * 256;
+            pool_sz[i & 1] = std::max(pool_sz[i & 1], need);
+        }
+        pool_base[0] = (char *)arena_.take(pool_sz[0]);
+        pool_base[1] = (char *)arena_.take(pool_sz[1]);
+    }
+
+    const float third = (float)(1.0 / (float)voc_.n_rb);            // src/hifigan.cpp:315
+    const float *prev_y[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < voc_.n_up; i++)
+    {
+        const int s = voc_.scales[i];
+        const ConvW &up = voc_.ups[i];
+        const int Cout = C >> 1, Cp = round_up(Cout, 16);
+        const int Lo = L * s;
+        DeviceArena pool;
+        pool.base = pool_base[i & 1];
+        pool.cap = pool_sz[i & 1];
+        float *ub = pool.take_n<float>((size_t)Lo * Cp);
+        float *y[3];
+        _Float16 *xt[3];
+        for (int j = 0; j < 3; j++) y[j] = pool.take_n<float>((size_t)Lo * Cp);
+        for (int j = 0; j < 3; j++) xt[j] = pool.take_n<_Float16>((size_t)Lo * Cp);
+
+        // V1: leaky_relu(0.1) -> transposed conv (polyphase) + bias      (src/hifigan.cpp:281-297, 22-71)
+        {
+            ConvJob j = job(up, L);
+            j.slope = 0.1f;
+            if (i == 0) { j.x0 = c0; j.pro = PRO_ACT; }
+            else { j.x0 = prev_y[0]; j.x1 = prev_y[1]; j.x2 = prev_y[2]; j.pro = PRO_SUM3_ACT; j.pscale = third; }
+            j.out = ub;
+            // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
+            conv(&j, 1, "voc_upsample", 4.0 * L * C * (i == 0 ? 1 : 3) + 4.0 * Lo * Cout + 2.0 * C * Cout * 2 * s,
+                 2.0 * L * C * Cout * 2 * s);
+        }
+        L = Lo;
+        C = Cout;
+
+        // V2: the 3 MRF branches run side by side (one job each); per dilation two launches
+        for (int d = 0; d < voc_.n_dil; d++)
+        {
+            ConvJob j1[3], j2[3];
+            double b1 = 0, f1 = 0, b2 = 0, f2 = 0;
+            for (int jb = 0; jb < 3; jb++)
+            {
+                const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
+                const float *yin = (d == 0) ? ub : y[jb];
+                // xt = lrelu(conv(lrelu(y), k, dil) + b)  kept as the f16 operand of the next conv (:108-150)
+                ConvJob a = job(rp.c1, L);
+                a.x0 = yin;
+                a.pro = PRO_ACT;
+                a.slope = 0.1f;
+                a.dil = voc_.dil[d];
+                a.pad = (rp.c1.K - 1) / 2 * voc_.dil[d];
+                a.eact = 1;
+                a.oslope = 0.1f;
+                a.out_f16 = 1;
+                a.out = xt[jb];
+                j1[jb] = a;
+                // y = y + (conv(xt, k, 1) + b)                                                    (:169-181)
+                ConvJob b = job(rp.c2, L);
+                b.x0 = xt[jb];
+                b.pro = PRO_RAW_F16;
+                b.res = yin;
+                b.ldres = Cp;
+                b.out = y[jb];
+                j2[jb] = b;
+                b1 += conv_bytes(L, C, C, rp.c1.K, false);
+                f1 += conv_flops(L, C, C, rp.c1.K);
+                b2 += conv_bytes(L, C, C, rp.c2.K, true);
+                f2 += conv_flops(L, C, C, rp.c2.K);
+            }
+            conv(j1, 3, "voc_resblock_conv", b1, f1);
+            conv(j2, 3, "voc_resblock_conv", b2, f2);
+        }
+        for (int jb = 0; jb < 3; jb++) prev_y[jb] = y[jb];
+    }
+
+    // V3: (sum of branches)/3 -> leaky_relu(0.01) -> conv k7 (C -> 1) + b -> tanh          (:315-345)
+    {
+        OutConvArgs a;
+        a.x0 = prev_y[0];
+        a.x1 = prev_y[1];
+        a.x2 = prev_y[2];
+        a.ldx = round_up(C, 16);
+        a.L = L;
+        a.C = C;
+        a.K = voc_.out_K;
+        a.pscale = third;
+        a.slope = (float)1e-2;
+        a.w = voc_.out_w;
+        a.bias = voc_.out_b;
+        a.out = d_wav;
+        ZV_LAUNCH("voc_output_conv", 12.0 * L * C + 4.0 * L, 2.0 * L * C * a.K, launch_out_conv(stream, a));
+    }
+}
+
+void Model::drop_graphs()
+{
+    for (auto &g : graphs_)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    graphs_.clear();
+}
+
+void Model::vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav)
+{
+    if (!graph_mode || profiling)
+    {
+        vocode_dev(d_mel, T, d_wav);
+        return;
+    }
+    for (auto &g : graphs_)
+        if (g.T == T && g.mel == d_mel && g.wav == d_wav)
+        {
+            ZV_HIP(hipGraphLaunch(g.exec, stream));
+            return;
+        }
+    arena_require(arena_bytes_for(1, T));        // outside the capture: hipMalloc is not capturable
+    hipGraph_t graph = nullptr;
+    ZV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try
+    {
+        vocode_dev(d_mel, T, d_wav);
+    }
+    catch (...)
+    {
+        hipStreamEndCapture(stream, &graph);
+        if (graph) hipGraphDestroy(graph);
+        throw;
+    }
+    ZV_HIP(hipStreamEndCapture(stream, &graph));
+    VocoderGraph vg;
+    vg.T = T;
+    vg.mel = d_mel;
+    vg.wav = d_wav;
+    hipError_t e = hipGraphInstantiate(&vg.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) fail(ZV_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    if (graphs_.size() >= 16) drop_graphs();
+    graphs_.push_back(vg);
+    ZV_HIP(hipGraphLaunch(vg.exec, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// StyleTTS mel decoder (reference src/stylettsdec.cpp:306-470)
+
+void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, float *d_mel)
+{
+    if (T == 0) fail(ZV_ERR_ARG, "T must be > 0");
+    arena_require(arena_bytes_for(1, T));
+    arena_.used = 0;
+    const int Ed = (int)E(), B = 2 * Ed, R = dec_.R, CAT = B + R, L = (int)T;
+    float *h = arena_.take_n<float>(dec_.fc_out + 64);
+    float *st1 = arena_.take_n<float>(2 * CAT + 64), *st2 = arena_.take_n<float>(2 * CAT + 64);
+    float *cat = arena_.take_n<float>((size_t)L * CAT);
+    float *t1 = arena_.take_n<float>((size_t)L * B);
+    float *sc = arena_.take_n<float>((size_t)L * B);
+    float *x0 = arena_.take_n<float>((size_t)L * B);
+    float *xa = arena_.take_n<float>((size_t)L * B);
+    float *asr_t = arena_.take_n<float>((size_t)L * R);
+
+    // D2: all ten AdaIN fc layers at once (depends only on the style vector)     (src/stylettsdec.cpp:175-189)
+    ZV_LAUNCH("dec_adain_fc", 4.0 * dec_.fc_out * (Ed + 2), 2.0 * dec_.fc_out * Ed,
+              launch_linear(stream, d_style, Ed, 1, Ed, dec_.fcW, dec_.fcB, dec_.fc_out, h, dec_.fc_out, dec_.fcExtra));
+
+    const float rsqrt2 = (float)(1.0 / sqrt(2.0));                       // src/stylettsdec.cpp:146,301
+
+    // one residual block: IN/AdaIN -> lrelu -> conv1 -> IN/AdaIN -> lrelu -> conv2 -> (+ shortcut) / sqrt2
+    auto block = [&](const DecBlk &b, const float *x, int ldx, const float *g1, const float *b1, const float *g2,
+                     const float *b2, float *out, int ldo) {
+        ZV_LAUNCH("dec_in_stats", 4.0 * L * b.cin, 3.0 * L * b.cin, launch_in_stats(stream, x, ldx, L, b.cin, 1e-5f, st1));
+        const float *res = x;
+        int ldres = ldx;
+        if (b.learned_sc)
+        {
+            ConvJob j = job(b.sc, L);
+            j.x0 = x;
+            j.ldx = ldx;
+            j.out = sc;
+            conv(&j, 1, "dec_conv", conv_bytes(L, b.cin, b.cout, 1, false), conv_flops(L, b.cin, b.cout, 1));
+            res = sc;
+            ldres = b.sc.Cout_p;
+        }
+        {
+            ConvJob j = job(b.conv1, L);
+            j.x0 = x;
+            j.ldx = ldx;
+            j.pro = PRO_NORM_ACT;
+            j.pstat = st1;
+            j.pa = g1;
+            j.pb = b1;
+            j.slope = 0.2f;
+            j.out = t1;
+            conv(&j, 1, "dec_conv", conv_bytes(L, b.cin, b.conv1.Cout, 3, false), conv_flops(L, b.cin, b.conv1.Cout, 3));
+        }
+        const int Cm = b.conv1.Cout;
+        ZV_LAUNCH("dec_in_stats", 4.0 * L * Cm, 3.0 * L * Cm, launch_in_stats(stream, t1, b.conv1.Cout_p, L, Cm, 1e-5f, st2));
+        {
+            ConvJob j = job(b.conv2, L);
+            j.x0 = t1;
+            j.ldx = b.conv1.Cout_p;
+            j.pro = PRO_NORM_ACT;
+            j.pstat = st2;
+            j.pa = g2;
+            j.pb = b2;
+            j.slope = 0.2f;
+            j.res = res;
+            j.ldres = ldres;
+            j.escale = rsqrt2;
+            j.out = out;
+            j.ldo = ldo;
+            conv(&j, 1, "dec_conv", conv_bytes(L, Cm, b.cout, 3, true), conv_flops(L, Cm, b.cout, 3));
+        }
+    };
+
+    // encode0 / encode1: ResBlk1d with affine InstanceNorm                         (src/stylettsdec.cpp:69-149,373-374)
+    block(dec_.enc[0], d_hidden, Ed, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, x0, B);
+    block(dec_.enc[1], x0, B, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, cat, CAT);
+
+    // asr_res = IN_affine(conv1x1(enc_seq) + b) written straight into the concat buffer      (:382-404)
+    {
+        ConvJob j = job(dec_.asr0, L);
+        j.x0 = d_hidden;
+        j.ldx = Ed;
+        j.out = asr_t;
+        conv(&j, 1, "dec_conv", conv_bytes(L, Ed, R, 1, false), conv_flops(L, Ed, R, 1));
+        ZV_LAUNCH("dec_in_stats", 4.0 * L * R, 3.0 * L * R, launch_in_stats(stream, asr_t, R, L, R, 1e-5f, st1));
+        ZV_LAUNCH("dec_norm_apply", 8.0 * L * R, 3.0 * L * R,
+                  launch_norm_apply(stream, asr_t, R, L, R, st1, dec_.asr1w, dec_.asr1b, cat + B, CAT));
+    }
+
+    // decode0..4: AdainResBlk1d; blocks 0..2 read cat([x, asr]) and 0,1 write x back into it   (:406-428)
+    const float *cur = cat;
+    int ldc = CAT;
+    float *outs[5] = {cat, cat, xa, x0, xa};
+    const int ldos[5] = {CAT, CAT, Ed, Ed, Ed};
+    for (int i = 0; i < 5; i++)
+    {
+        const DecBlk &b = dec_.dec[i];
+        block(b, cur, ldc, h + b.g1, h + b.g1 + b.cin, h + b.g2, h + b.g2 + b.cout, outs[i], ldos[i]);
+        cur = outs[i];
+        ldc = ldos[i];
+    }
+    // to_out: conv1x1 E -> num_mels + b, emitted frame-major                                       (:432-441)
+    {
+        ConvJob j = job(dec_.to_out, L);
+        j.x0 = cur;
+        j.ldx = ldc;
+        j.out = d_mel;
+        j.ldo = dec_.M;
+        conv(&j, 1, "dec_conv", conv_bytes(L, Ed, dec_.M, 1, false), conv_flops(L, Ed, dec_.M, 1));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FastSpeech2 encoder + variance adaptor + length regulator (reference src/fs2encoder.cpp:289-336,477-656)
+
+Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N,
+                                     uint32_t T, float *d_hidden)
+{
+    if (N == 0 || T == 0) fail(ZV_ERR_ARG, "N and T must be > 0");
+    if ((int)N > enc_.posenc_rows) fail(ZV_ERR_ARG, "%u phonemes exceed the %d rows of the sinusoid table", N, enc_.posenc_rows);
+    arena_require(arena_bytes_for(N, T));
+    arena_.used = 0;
+    const int Ed = (int)E(), n = (int)N, H = hp.encoder_head, dk = Ed / H;
+    const int Fp = round_up(hp.conv_filter_size, 16);
+    float *x = arena_.take_n<float>((size_t)n * Ed), *y = arena_.take_n<float>((size_t)n * Ed);
+    float *qkv = arena_.take_n<float>((size_t)n * 3 * Ed), *o = arena_.take_n<float>((size_t)n * Ed);
+    float *f = arena_.take_n<float>((size_t)n * Ed);
+    _Float16 *hh = arena_.take_n<_Float16>((size_t)n * Fp);
+    const int Vp = round_up(enc_.dur.V, 16);
+    float *va = arena_.take_n<float>((size_t)n * Vp), *vb = arena_.take_n<float>((size_t)n * Vp);
+    EncoderTaps t;
+    t.features = x;
+    t.logdur = arena_.take_n<float>(n);
+    t.pitch = arena_.take_n<float>(n);
+    t.energy = arena_.take_n<float>(n);
+    t.pitch_bucket = arena_.take_n<int32_t>(n);
+    t.energy_bucket = arena_.take_n<int32_t>(n);
+    t.n_frames = arena_.take_n<int32_t>(n + 1);
+
+    ZV_LAUNCH("enc_embed", 8.0 * n * Ed, 1.0 * n * Ed,
+              launch_embed(stream, d_ids, d_puncts, enc_.wemb, hp.emb_dim, enc_.pemb, hp.punct_emb_dim, enc_.posenc, n, x, Ed));
+    const float temperature = (float)pow((double)dk, 0.5);               // src/fs2encoder.cpp:66
+    const float inv_t = (float)(1.0 / temperature);                      // :107
+    for (const EncLayer &Ly : enc_.layers)
+    {
+        ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * n * Ed), 6.0 * n * Ed * Ed,
+                  launch_linear(stream, x, Ed, n, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr));
+        ZV_LAUNCH("enc_attention", 16.0 * n * Ed, 4.0 * n * n * Ed,
+                  launch_attention(stream, qkv, qkv + Ed, qkv + 2 * Ed, 3 * Ed, n, H, dk, inv_t, o, Ed));
+        ZV_LAUNCH("enc_linear", 4.0 * (1.0 * Ed * Ed + 2.0 * n * Ed), 2.0 * n * Ed * Ed,
+                  launch_linear(stream, o, Ed, n, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr));
+        ZV_LAUNCH("enc_layernorm", 12.0 * n * Ed, 8.0 * n * Ed,
+                  launch_add_layernorm(stream, f, Ed, x, Ed, n, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed));
+        {   // FFN: conv k9 + b -> relu (kept as f16 operand) -> conv k1 + b            (src/fs2encoder.cpp:190-214)
+            ConvJob a = job(Ly.w1, n);
+            a.x0 = y;
+            a.eact = 1;
+            a.oslope = 0.f;
+            a.out_f16 = 1;
+            a.out = hh;
+            conv(&a, 1, "enc_conv", conv_bytes(n, Ed, Ly.w1.Cout, Ly.w1.K, false), conv_flops(n, Ed, Ly.w1.Cout, Ly.w1.K));
+            ConvJob b = job(Ly.w2, n);
+            b.x0 = hh;
+            b.pro = PRO_RAW_F16;
+            b.out = f;
+            conv(&b, 1, "enc_conv", conv_bytes(n, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(n, Ly.w1.Cout, Ed, Ly.w2.K));
+        }
+        ZV_LAUNCH("enc_layernorm", 12.0 * n * Ed, 8.0 * n * Ed,
+                  launch_add_layernorm(stream, f, Ed, y, Ed, n, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed));
+    }
+    // features = encoder output + style_embed                                             (:550-552)
+    ZV_LAUNCH("enc_add_style", 8.0 * n * Ed, 1.0 * n * Ed, launch_add_rowvec(stream, x, Ed, n, Ed, d_style));
+
+    auto predictor = [&](const VarPred &v, float *out) {        // VariancePredictor::graph (:386-440)
+        ConvJob a = job(v.c1, n);
+        a.x0 = x;
+        a.eact = 1;
+        a.oslope = 0.f;
+        a.out = va;
+        conv(&a, 1, "enc_conv", conv_bytes(n, Ed, v.V, 3, false), conv_flops(n, Ed, v.V, 3));
+        ZV_LAUNCH("enc_layernorm", 8.0 * n * v.V, 8.0 * n * v.V,
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, n, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp));
+        ConvJob b = job(v.c2, n);
+        b.x0 = vb;
+        b.pad = 1;                                              // literal 1 in the reference (:417)
+        b.eact = 1;
+        b.oslope = 0.f;
+        b.out = va;
+        conv(&b, 1, "enc_conv", conv_bytes(n, v.V, v.V, 3, false), conv_flops(n, v.V, v.V, 3));
+        ZV_LAUNCH("enc_layernorm", 8.0 * n * v.V, 8.0 * n * v.V,
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, n, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp));
+        ZV_LAUNCH("enc_rowdot", 4.0 * n * v.V, 2.0 * n * v.V, launch_rowdot(stream, vb, Vp, n, v.V, v.lw, v.lb, out));
+    };
+    predictor(enc_.dur, t.logdur);
+    predictor(enc_.pitch, t.pitch);
+    ZV_LAUNCH("enc_bucket_embed", 12.0 * n * Ed, 1.0 * n * Ed,
+              launch_bucket_embed_add(stream, t.pitch, n, hp.encoder_ve_n_bins, enc_.pitch_emb, Ed, x, Ed, t.pitch_bucket));
+    predictor(enc_.energy, t.energy);                           // sees the pitch-augmented features (:569-572)
+    ZV_LAUNCH("enc_bucket_embed", 12.0 * n * Ed, 1.0 * n * Ed,
+              launch_bucket_embed_add(stream, t.energy, n, hp.encoder_ve_n_bins, enc_.energy_emb, Ed, x, Ed, t.energy_bucket));
+    ZV_LAUNCH("enc_length_regulator", 4.0 * (n + T) * Ed, 0.0,
+              launch_length_regulator(stream, x, Ed, t.logdur, n, Ed, (int)T, d_hidden, Ed, t.n_frames));
+    return t;
+}
+
+}  // namespace zv

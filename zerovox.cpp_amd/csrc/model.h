@@ -1,0 +1,177 @@
+// model.h — the model object behind zv_model: GGUF weights re-laid-out in HBM, a static activation
+// arena and the fixed kernel schedule of the three stages.
+//
+// Replaces ZeroVOXModel's loader (reference src/zerovox.cpp:21-179) and the three ggml graphs built in
+// the stage constructors (src/fs2encoder.cpp:477-586, src/stylettsdec.cpp:306-449, src/hifigan.cpp:187-356).
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gguf_reader.h"
+#include "kernels.h"
+
+namespace zv
+{
+
+// one Conv1d layer resident in HBM: weights in MFMA fragment order, bias padded with zeros
+struct ConvW
+{
+    void  *w = nullptr;
+    float *bias = nullptr;
+    int    K = 0, Cin = 0, Cout = 0, Cin_p = 0, Cout_p = 0, ck = 0;
+};
+
+struct DeviceArena
+{
+    char  *base = nullptr;
+    size_t cap = 0, used = 0;
+    void  *take(size_t bytes)
+    {
+        const size_t a = (used + 255) & ~(size_t)255;
+        if (a + bytes > cap) fail(ZV_ERR_OOM, "device arena overflow (%zu + %zu > %zu)", a, bytes, cap);
+        used = a + bytes;
+        return base + a;
+    }
+    template <typename T> T *take_n(size_t n) { return (T *)take(n * sizeof(T)); }
+};
+
+struct ProfEntry
+{
+    const char *name;
+    hipEvent_t  e0, e1;
+    double      bytes, flops;
+};
+
+struct VocoderGraph
+{
+    uint32_t        T = 0;
+    const float    *mel = nullptr;
+    float          *wav = nullptr;
+    hipGraphExec_t  exec = nullptr;
+};
+
+class Model
+{
+  public:
+    Model(const std::string &gguf_path, int device);
+    ~Model();
+
+    zv_hparams hp{};
+    int        device = 0;
+    int        n_cu = 256;
+    hipStream_t stream = nullptr;
+
+    // ---- stages (device pointers in, device pointers out; everything enqueued on `stream`) ----
+    void vocode_dev(const float *d_mel, uint32_t T, float *d_wav);
+    void decode_dev(const float *d_hidden, const float *d_style, uint32_t T, float *d_mel);
+    // d_hidden [T][E]; taps are device pointers inside the arena, valid until the next call
+    struct EncoderTaps
+    {
+        float   *features = nullptr, *logdur = nullptr, *pitch = nullptr, *energy = nullptr;
+        int32_t *pitch_bucket = nullptr, *energy_bucket = nullptr, *n_frames = nullptr;
+    };
+    EncoderTaps encode_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
+                           float *d_hidden);
+
+    void reserve(uint32_t max_phonemes, uint32_t max_frames);
+    void sync();
+
+    // scratch for host-buffer entry points (grows on demand)
+    void *io_scratch(size_t bytes);
+
+    // graph replay of the vocoder schedule
+    bool graph_mode = false;
+    void vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav);
+
+    // profiling (HIP events around every launch while enabled)
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    void prof_clear();
+
+    uint32_t E() const { return hp.emb_dim + hp.punct_emb_dim; }
+
+  private:
+    // ---- weights ----
+    std::vector<void *> allocs_;
+    void  *dev_alloc(size_t bytes);
+    float *upload_f32(const GgufTensor &t, int pad_to = 0, float pad_value = 0.f);
+    float *upload_vec(const GgufFile &g, const std::string &name, int expect_n, int pad_to = 0, float pad_value = 0.f);
+    ConvW  load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin = -1);
+    ConvW  load_upsample(const GgufFile &g, int idx, int stride, int expect_cin);
+
+    struct ResPair { ConvW c1, c2; };
+    struct Voc
+    {
+        float *mean = nullptr, *scale = nullptr;
+        ConvW  in_conv;
+        int    n_up = 0;
+        int    scales[8] = {0};
+        ConvW  ups[8];
+        int    n_rb = 0, n_dil = 3;
+        int    dil[8] = {1, 3, 5};
+        std::vector<ResPair> pairs;       // [(stage*n_rb + j)*n_dil + d]
+        uint16_t *out_w = nullptr;        // f16 [K][Cp]
+        float  out_b = 0.f;
+        int    out_K = 0, out_C = 0;
+    } voc_;
+
+    struct DecBlk
+    {
+        ConvW  conv1, conv2, sc;
+        bool   learned_sc = false;
+        int    cin = 0, cout = 0;
+        float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;   // encode blocks: affine IN
+        int    g1 = 0, g2 = 0;                                                   // decode blocks: offsets into adain h
+    };
+    struct Dec
+    {
+        DecBlk enc[2], dec[5];
+        ConvW  asr0, to_out;
+        float *asr1w = nullptr, *asr1b = nullptr;
+        float *fcW = nullptr, *fcB = nullptr, *fcExtra = nullptr;   // all 10 AdaIN fc layers concatenated
+        int    fc_out = 0;
+        int    R = 64, M = 80;
+    } dec_;
+
+    struct EncLayer
+    {
+        float *qkvW = nullptr, *qkvB = nullptr, *fcW = nullptr, *fcB = nullptr;
+        float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+        ConvW  w1, w2;
+    };
+    struct VarPred
+    {
+        ConvW  c1, c2;
+        float *l1w = nullptr, *l1b = nullptr, *l2w = nullptr, *l2b = nullptr, *lw = nullptr, *lb = nullptr;
+        int    V = 0;
+    };
+    struct Enc
+    {
+        float *wemb = nullptr, *pemb = nullptr, *posenc = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr;
+        int    posenc_rows = 0;
+        std::vector<EncLayer> layers;
+        VarPred dur, pitch, energy;
+    } enc_;
+
+    // ---- activations ----
+    DeviceArena arena_;
+    void  arena_require(size_t bytes);
+    size_t arena_bytes_for(uint32_t N, uint32_t T) const;
+    void *io_ = nullptr;
+    size_t io_cap_ = 0;
+
+    // ---- launch helpers ----
+    void conv(const ConvJob *jobs, int n, const char *name, double bytes, double flops);
+    ConvJob job(const ConvW &w, int L) const;
+    void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
+    void tock(hipEvent_t e0, const char *name, double bytes, double flops);
+
+    std::vector<VocoderGraph> graphs_;
+    void drop_graphs();
+};
+
+}  // namespace zv

@@ -224,7 +224,10 @@ def make_tensors(g: Geometry, seed: int) -> List[Tuple[str, np.ndarray]]:
     conv_w("_mel_decoder.to_out.0.w", g.num_mels, E, 1)
     vec("_mel_decoder.to_out.0.b", g.num_mels)
 
-    # ---- HiFi-GAN vocoder (channels halve per upsample stage)
+    # ---- HiFi-GAN vocoder (channels halve per upsample stage).  Gains are chosen so that the waveform has a
+    # speech-like level (RMS ~0.1, peaks ~0.35): the reference's re-association noise floor is a fixed
+    # *relative* ~4.5e-4 of the signal (f16 operand rounding, SURVEY.md Appx D), so the absolute 1e-4 RMS
+    # gate only means something at a realistic amplitude.
     C = g.voc_channels
     conv_w("_meldec.input_conv.w", C, g.num_mels, g.voc_kernel_size)
     vec("_meldec.input_conv.b", C)
@@ -233,14 +236,14 @@ def make_tensors(g: Geometry, seed: int) -> List[Tuple[str, np.ndarray]]:
         # stored already flipped + permuted to (out, in, k) (utils/zv2gguf.py:175-178); a transposed
         # conv of stride s uses k/s taps per output sample, hence fan-in ci*k/s
         amp_gain = np.sqrt(s)
-        conv_w(f"_meldec.upsamples.{i}.1.w", co, ci, k, gain=1.2 * amp_gain)
+        conv_w(f"_meldec.upsamples.{i}.1.w", co, ci, k, gain=1.0 * amp_gain)
         vec(f"_meldec.upsamples.{i}.1.b", co)
         for j, rk in enumerate(g.resblock_kernels):
             n = i * len(g.resblock_kernels) + j
             for d in range(len(g.resblock_dilations)):
-                conv_w(f"_meldec.blocks.{n}.convs1.{d}.1.w", co, co, rk, gain=1.2)
+                conv_w(f"_meldec.blocks.{n}.convs1.{d}.1.w", co, co, rk, gain=1.0)
                 vec(f"_meldec.blocks.{n}.convs1.{d}.1.b", co)
-                conv_w(f"_meldec.blocks.{n}.convs2.{d}.1.w", co, co, rk, gain=0.6)
+                conv_w(f"_meldec.blocks.{n}.convs2.{d}.1.w", co, co, rk, gain=0.2)
                 vec(f"_meldec.blocks.{n}.convs2.{d}.1.b", co)
     cl = C >> len(g.upsample_scales)
     conv_w("_meldec.output_conv.1.w", 1, cl, g.voc_kernel_size, gain=0.5)
