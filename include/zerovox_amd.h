@@ -127,6 +127,13 @@ zv_status zv_profile_begin(zv_model *m);
 /* stops profiling, copies up to cap entries, returns the entry count in *n */
 zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint32_t *n);
 
+/* ---- GGUF inspection without a device (loader half of the boundary; used by the CPU test-suite) ----
+ * Parses the file exactly as zv_model_load does and reports the counts; *max_seq_len receives the
+ * `<arch>.max_seq_len` KV.  tensor_index >= 0 additionally returns that tensor's name (<= 63 chars + NUL),
+ * ggml type code and shape (ne[4], missing dims = 1). */
+zv_status zv_gguf_inspect(const char *gguf_path, uint32_t *n_tensors, uint32_t *max_seq_len, int tensor_index,
+                          char *name_out, uint32_t *type_out, int64_t *ne_out);
+
 /* ---- "next" row f-2: WAV writer (PCM16 mono, 44-byte RIFF header) --------------------------- */
 zv_status zv_write_wav(const char *path, const float *wav, size_t n_samples, uint32_t sampling_rate);
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures from the compiled reference (oracle/_ref/zvref).
+
+Run in the build container only (it needs /root/reference to have been compiled by `make -C oracle ref`):
+    python tests/golden/make_golden.py
+Fixtures hold inputs' *recipes* (geometry, seeds — inputs are regenerated bit-identically by
+zerovox.cpp_amd/synth.py) and the reference's OUTPUTS: in full for the small geometries, as strided
+samples + SHA-256 of the full f32 buffer for the full-size configs of BASELINE.json.  ISA of the
+reference build: x86-64-v3 (AVX2+FMA+F16C), 4 threads (results do not depend on the thread count).
+Also slices the reference's only own known-answer data, utils/norm1dexample.json (InstanceNorm1d pair).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from zerovox_cpp_amd import gguf, synth  # noqa: E402
+from oracle import zvoracle  # noqa: E402
+
+SEED_W = 1234
+STRIDE = 61      # prime stride for the sampled goldens
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def case(geom_name, T, N, full, tmp="/tmp"):
+    g = synth.GEOMETRIES[geom_name]
+    path = os.path.join(tmp, f"golden_{geom_name}.gguf")
+    synth.write_checkpoint(path, g, SEED_W)
+    _, tensors = gguf.read_gguf(path)
+    mel_in = synth.vocoder_mel(g, tensors, 7, T)
+    hid_in = synth.decoder_hidden(g, 11, T)
+    ids, puncts, style = synth.encoder_inputs(g, 5, N)
+    v = zvoracle.run_reference(path, T=T, voc=mel_in)
+    d = zvoracle.run_reference(path, T=T, dec=(hid_in, style))
+    e = zvoracle.run_reference(path, T=T, N=N, enc=(ids, puncts, style), E=g.E)
+    out = dict(geometry=geom_name, seed_w=SEED_W, T=T, N=N, seed_mel=7, seed_hidden=11, seed_enc=5, stride=STRIDE,
+               wav_sha256=sha(v["wav"]), mel_sha256=sha(d["mel"]), hidden_sha256=sha(e["hidden"]),
+               features_sha256=sha(e["features"]), logdur=e["logdur"], energy=e["energy"],
+               pitch_bucket=e["pitch_bucket"], energy_bucket=e["energy_bucket"], n_frames=e["n_frames"],
+               wav_rms=float(np.sqrt(np.mean(v["wav"].astype(np.float64) ** 2))),
+               mel_rms=float(np.sqrt(np.mean(d["mel"].astype(np.float64) ** 2))))
+    if full:
+        out.update(wav=v["wav"], mel=d["mel"], hidden=e["hidden"], features=e["features"])
+    else:
+        out.update(wav_samples=v["wav"][::STRIDE].copy(), mel_samples=d["mel"].reshape(-1)[::STRIDE].copy(),
+                   hidden_samples=e["hidden"].reshape(-1)[::STRIDE].copy(),
+                   features_samples=e["features"].reshape(-1)[::STRIDE].copy())
+    np.savez_compressed(os.path.join(HERE, f"{geom_name}_T{T}_N{N}.npz"), **out)
+    print(geom_name, T, N, "frames", e["n_frames"], "wav rms", out["wav_rms"])
+    os.remove(path)
+
+
+def norm_kat():
+    src = "/root/reference/utils/norm1dexample.json"
+    if not os.path.exists(src):
+        return
+    j = json.load(open(src))
+    x_in, x_out = np.array(j["x_in"], np.float32)[0], np.array(j["x_out"], np.float32)[0]
+    w, b = np.array(j["weight"], np.float32), np.array(j["bias"], np.float32)
+    sel = np.arange(0, x_in.shape[0], 16)
+    np.savez_compressed(os.path.join(HERE, "instnorm1d_kat.npz"), x_in=x_in[sel], x_out=x_out[sel], weight=w[sel], bias=b[sel],
+                        channels=sel)
+    print("instnorm KAT:", x_in[sel].shape)
+
+
+if __name__ == "__main__":
+    if not zvoracle.have_reference():
+        sys.exit("oracle/_ref/zvref missing: run `make -C oracle ref` first")
+    case("tiny", 40, 10, full=True)
+    case("small", 64, 16, full=True)
+    case("medium", 512, 64, full=False)      # BASELINE.json configs[0] (N=64) and [1] (vocoder, 512 frames)
+    case("medium", 512, 128, full=False)     # configs[2]
+    norm_kat()

@@ -1,0 +1,132 @@
+"""CPU: the drop-in boundary without a GPU — the C-ABI library loads and exports every declared symbol,
+the product's C++ GGUF reader parses what the contract says, errors map to status codes, the WAV writer and
+the synthetic-checkpoint generator are deterministic."""
+import hashlib
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from zerovox_cpp_amd import capi
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, "include", "zerovox_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(zv_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/zerovox_amd.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared
+    assert b"gfx950" in lib.zv_version()
+
+
+def test_facade_header_mirrors_reference_signatures():
+    """same class names and eval() signatures as the reference's src/zerovox.h:191,323,378,408-413"""
+    h = open(os.path.join(ROOT, "zerovox.cpp_amd", "csrc", "zerovox.h")).read()
+    flat = re.sub(r"\s+", " ", h)
+    assert "uint32_t eval(const int32_t *src_seq_data, const int32_t *puncts_data, const float *style_embed_data, uint32_t num_phonemes, float *x);" in flat
+    assert "void eval(const float *enc_seq_data, const float *spk_emb_data, float *mel);" in flat
+    assert "void eval(const float *mel, float *wav);" in flat
+    assert "ZeroVOXModel(const std::string &fname);" in flat and "bool write_wav_file(const std::string &fname);" in flat
+    for cls in ("class FS2Encoder", "class StyleTTSDecoder", "class HiFiGAN", "class ZeroVOXModel"):
+        assert cls in h
+
+
+def test_cpp_gguf_reader_matches_contract(tmp_path):
+    from zerovox_cpp_amd import capi, gguf, synth
+    for trim in (False, True):
+        p = str(tmp_path / f"t{int(trim)}.gguf")
+        synth.write_checkpoint(p, synth.TINY, 5, trim_dims=trim)
+        _, tensors = gguf.read_gguf(p)
+        n, T = capi.gguf_inspect(p)
+        assert n == len(tensors) == 291 and T == synth.TINY.max_seq_len
+        names = list(tensors)
+        for i in (0, 1, 2, 57, n - 1):
+            _, _, name, typ, ne = capi.gguf_inspect(p, i)
+            arr = tensors[names[i]]
+            assert name == names[i]
+            assert typ == {np.dtype(np.float32): 0, np.dtype(np.float16): 1}[arr.dtype]
+            assert ne == list(arr.shape[::-1]) + [1] * (4 - arr.ndim)       # missing dims padded with 1
+
+
+def test_gguf_error_mapping(tmp_path):
+    from zerovox_cpp_amd import capi, gguf, synth
+    with pytest.raises(capi.ZvError) as e:
+        capi.gguf_inspect(str(tmp_path / "missing.gguf"))
+    assert e.value.status == 1                                   # ZV_ERR_IO
+    bad = tmp_path / "bad.gguf"
+    bad.write_bytes(b"GGUX" + b"\0" * 64)
+    with pytest.raises(capi.ZvError) as e:
+        capi.gguf_inspect(str(bad))
+    assert e.value.status == 2                                   # ZV_ERR_FORMAT
+    good = str(tmp_path / "g.gguf")
+    synth.write_checkpoint(good, synth.TINY, 5)
+    data = open(good, "rb").read()
+    trunc = tmp_path / "trunc.gguf"
+    trunc.write_bytes(data[: len(data) // 2])
+    with pytest.raises(capi.ZvError) as e:
+        capi.gguf_inspect(str(trunc))
+    assert e.value.status == 2
+    v2 = tmp_path / "v2.gguf"
+    v2.write_bytes(data[:4] + struct.pack("<I", 2) + data[8:])
+    with pytest.raises(capi.ZvError) as e:
+        capi.gguf_inspect(str(v2))
+    assert e.value.status == 2 and "version" in str(e.value)
+    # a required KV missing -> ZV_ERR_MISSING (the reference exit(1)s here, src/zerovox.h:452-454)
+    kv = synth.TINY.kv()
+    kv.pop("zerovox-resnet-fs2-styletts.max_seq_len")
+    nokey = str(tmp_path / "nokey.gguf")
+    gguf.write_gguf(nokey, kv, synth.make_tensors(synth.TINY, 5)[:3])
+    with pytest.raises(capi.ZvError) as e:
+        capi.gguf_inspect(nokey)
+    assert e.value.status == 3
+
+
+def test_model_load_fails_loudly_without_gpu(tmp_path):
+    """no CPU fallback: without a gfx950 device zv_model_load must fail with ZV_ERR_DEVICE"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from zerovox_cpp_amd import capi, synth
+    p = str(tmp_path / "t.gguf")
+    synth.write_checkpoint(p, synth.TINY, 5)
+    with pytest.raises(capi.ZvError) as e:
+        capi.Model(p, 0)
+    assert e.value.status == 6
+
+
+def test_wav_writer(tmp_path):
+    from zerovox_cpp_amd import capi
+    wav = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 1.5, -1.5, 1e-5], np.float32)
+    p = str(tmp_path / "o.wav")
+    capi.write_wav(p, wav, 22050)
+    b = open(p, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data"
+    fmt, ch, sr, br, ba, bits = struct.unpack("<HHIIHH", b[20:36])
+    assert (fmt, ch, sr, br, ba, bits) == (1, 1, 22050, 44100, 2, 16)
+    assert struct.unpack("<I", b[40:44])[0] == 16 and struct.unpack("<I", b[4:8])[0] == 36 + 16
+    pcm = np.frombuffer(b[44:], np.int16)
+    assert pcm.tolist() == [0, 16384, -16384, 32767, -32767, 32767, -32768, 0]
+
+
+def test_synthetic_checkpoint_is_deterministic():
+    """the GPU box regenerates the goldens' checkpoints from (geometry, seed): pin the generator"""
+    from zerovox_cpp_amd import synth
+    t = dict(synth.make_tensors(synth.TINY, 1234))
+    h = hashlib.sha256()
+    for k in sorted(t):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(t[k]).tobytes())
+    assert h.hexdigest() == PINNED_TINY_SHA256, h.hexdigest()
+    u = synth.u01(7, "x", 4)
+    assert np.allclose(u, synth.u01(7, "x", 4)) and not np.allclose(u, synth.u01(8, "x", 4))
+    ids, puncts, style = synth.encoder_inputs(synth.TINY, 5, 200)
+    assert ids.min() >= 1 and ids.max() <= 154 and puncts.min() >= 0 and puncts.max() <= 6
+
+
+PINNED_TINY_SHA256 = "b7573a897ac23670e07dd746b9e3be836911ebd22bd02463eeefe2853c457d68"

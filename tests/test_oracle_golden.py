@@ -1,0 +1,128 @@
+"""CPU: the oracle (oracle/zv_oracle.c) against the golden vectors produced by the compiled reference.
+
+The fixtures under tests/golden/ are OUTPUTS OF THE REFERENCE ITSELF (tests/golden/make_golden.py drives
+oracle/_ref/zvref = the unmodified stage classes on ggml-CPU).  The oracle must reproduce them bit for bit
+(ZVO_ORDER_GGML_AVX2).  Where oracle/_ref exists (it travels to the GPU box as a prebuilt binary) the same
+is checked live on fresh seeds."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _inputs(g, tensors, z):
+    from zerovox_cpp_amd import synth
+    T, N = int(z["T"]), int(z["N"])
+    mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
+    hid = synth.decoder_hidden(g, int(z["seed_hidden"]), T)
+    ids, puncts, style = synth.encoder_inputs(g, int(z["seed_enc"]), N)
+    return T, N, mel, hid, ids, puncts, style
+
+
+@pytest.mark.parametrize("fixture", ["tiny_T40_N10.npz", "small_T64_N16.npz"])
+def test_oracle_reproduces_reference_full(ckpt, fixture):
+    from oracle import zvoracle
+    z = np.load(os.path.join(GOLD, fixture))
+    path, g, tensors = ckpt(str(z["geometry"]), int(z["seed_w"]))
+    T, N, mel, hid, ids, puncts, style = _inputs(g, tensors, z)
+    orc = zvoracle.Oracle(tensors)
+    assert np.array_equal(orc.vocoder(mel), z["wav"])
+    assert np.array_equal(orc.decoder(hid, style), z["mel"])
+    e = orc.encoder(g, ids, puncts, style, T)
+    assert np.array_equal(e["hidden"], z["hidden"])
+    assert np.array_equal(e["features"], z["features"])
+    assert np.array_equal(e["logdur"], z["logdur"])
+    assert np.array_equal(e["energy"], z["energy"])
+    assert np.array_equal(e["pitch_bucket"], z["pitch_bucket"])
+    assert np.array_equal(e["energy_bucket"], z["energy_bucket"])
+    assert e["n_frames"] == int(z["n_frames"])
+
+
+@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz"])
+def test_oracle_reproduces_reference_full_size(ckpt, fixture):
+    """BASELINE.json configs[0..2] at full size: SHA-256 of the whole buffers + strided samples"""
+    from oracle import zvoracle
+    z = np.load(os.path.join(GOLD, fixture))
+    path, g, tensors = ckpt("medium", int(z["seed_w"]))
+    T, N, mel, hid, ids, puncts, style = _inputs(g, tensors, z)
+    s = int(z["stride"])
+    orc = zvoracle.Oracle(tensors)
+    e = orc.encoder(g, ids, puncts, style, T)
+    assert e["n_frames"] == int(z["n_frames"])
+    assert np.array_equal(e["pitch_bucket"], z["pitch_bucket"]) and np.array_equal(e["energy_bucket"], z["energy_bucket"])
+    assert np.array_equal(e["logdur"], z["logdur"])
+    assert np.array_equal(e["hidden"].reshape(-1)[::s], z["hidden_samples"])
+    assert sha(e["hidden"]) == str(z["hidden_sha256"])
+    if N == 64:        # decoder / vocoder inputs do not depend on N: check them once
+        d = orc.decoder(hid, style)
+        assert np.array_equal(d.reshape(-1)[::s], z["mel_samples"]) and sha(d) == str(z["mel_sha256"])
+        w = orc.vocoder(mel)
+        assert np.array_equal(w[::s], z["wav_samples"]) and sha(w) == str(z["wav_sha256"])
+
+
+def test_oracle_vs_live_reference_fresh_seed(tmp_path):
+    """different weights seed + ragged sizes, compared live against oracle/_ref when it is present"""
+    from zerovox_cpp_amd import gguf, synth
+    from oracle import zvoracle
+    if not zvoracle.have_reference():
+        pytest.skip("oracle/_ref/zvref not built on this machine")
+    g = synth.TINY
+    path = str(tmp_path / "t.gguf")
+    synth.write_checkpoint(path, g, 99, trim_dims=True)      # ggml-C-writer style n_dims
+    _, tensors = gguf.read_gguf(path)
+    orc = zvoracle.Oracle(tensors)
+    for T, N in ((7, 3), (33, 17)):
+        mel = synth.vocoder_mel(g, tensors, 21, T)
+        hid = synth.decoder_hidden(g, 22, T)
+        ids, puncts, style = synth.encoder_inputs(g, 23, N)
+        assert np.array_equal(orc.vocoder(mel), zvoracle.run_reference(path, T=T, voc=mel)["wav"])
+        assert np.array_equal(orc.decoder(hid, style), zvoracle.run_reference(path, T=T, dec=(hid, style))["mel"])
+        r = zvoracle.run_reference(path, T=T, N=N, enc=(ids, puncts, style), E=g.E)
+        e = orc.encoder(g, ids, puncts, style, T)
+        for k in ("hidden", "features", "logdur", "energy", "pitch_bucket", "energy_bucket"):
+            assert np.array_equal(e[k], r[k]), k
+        assert e["n_frames"] == r["n_frames"]
+
+
+def test_instancenorm_known_answer():
+    """the reference repo's only own golden data: utils/norm1dexample.json (PyTorch InstanceNorm1d(affine) pair,
+    weights rounded to 4 decimals in the file -> 2e-4 tolerance)"""
+    from oracle import zvoracle
+    z = np.load(os.path.join(GOLD, "instnorm1d_kat.npz"))
+    orc = zvoracle.Oracle({})
+    y = orc.norm_rows(z["x_in"]) * z["weight"][:, None] + z["bias"][:, None]
+    assert np.max(np.abs(y - z["x_out"])) < 2e-4
+
+
+def test_length_regulator_edge_cases():
+    from oracle import zvoracle
+    orc = zvoracle.Oracle({})
+    feat = np.arange(12, dtype=np.float32).reshape(3, 4)
+    # durations: exp(ld)-1 -> 0.4 (-> 0), 2.5 (-> 3: truncating x+0.5, not half-even), 100 (clipped at T)
+    ld = np.log(np.array([1.4, 3.5, 101.0], np.float32)).astype(np.float32)
+    hid, nf = orc.length_regulator(feat, ld, 6)
+    assert nf == 6 and np.array_equal(hid[:3], np.repeat(feat[1:2], 3, 0)) and np.array_equal(hid[3:], np.repeat(feat[2:3], 3, 0))
+    hid, nf = orc.length_regulator(feat, np.full(3, -5, np.float32), 4)
+    assert nf == 0 and not hid.any()
+
+
+def test_oracle_self_noise_floor(ckpt):
+    """re-association noise of the reference semantics (SURVEY.md Appx D): bounded, and the reason GPU gates are
+    noise-aware.  wav floor stays well under the 1e-4 RMS gate at speech-like amplitude."""
+    from zerovox_cpp_amd import synth
+    from oracle import zvoracle
+    path, g, tensors = ckpt("small")
+    mel = synth.vocoder_mel(g, tensors, 7, 32)
+    orc = zvoracle.Oracle(tensors)
+    a = orc.vocoder(mel)
+    orc.set_order(zvoracle.ORDER_SEQ_F32)
+    b = orc.vocoder(mel)
+    floor = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
+    assert 0 < floor < 6e-5

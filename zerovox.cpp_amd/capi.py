@@ -19,7 +19,7 @@ SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
-    "zv_profile_begin", "zv_profile_end", "zv_write_wav",
+    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect",
 ]
 
 
@@ -81,6 +81,8 @@ def load_library(path: Optional[str] = None):
     lib.zv_profile_begin.argtypes = [vp]
     lib.zv_profile_end.argtypes = [vp, C.POINTER(KernelStat), u32, C.POINTER(u32)]
     lib.zv_write_wav.argtypes = [C.c_char_p, fp, C.c_size_t, u32]
+    lib.zv_gguf_inspect.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.c_int, C.c_char_p, C.POINTER(u32),
+                                    C.POINTER(C.c_int64)]
     if path is None:
         _lib = lib
     return lib
@@ -202,6 +204,20 @@ class Model:
         self._chk(self.lib.zv_profile_end(self.h, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
                      algo_bytes=arr[i].algo_bytes, algo_flops=arr[i].algo_flops) for i in range(min(cap, n.value))]
+
+
+def gguf_inspect(path: str, tensor_index: int = -1):
+    """(n_tensors, max_seq_len[, name, ggml_type, ne]) as parsed by the product's C++ GGUF reader (no GPU needed)."""
+    lib = load_library()
+    n, T, typ = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    name = C.create_string_buffer(64)
+    ne = (C.c_int64 * 4)()
+    st = lib.zv_gguf_inspect(path.encode(), C.byref(n), C.byref(T), tensor_index, name, C.byref(typ), ne)
+    if st != 0:
+        raise ZvError(st, lib.zv_last_error().decode())
+    if tensor_index < 0:
+        return n.value, T.value
+    return n.value, T.value, name.value.decode(), typ.value, list(ne)
 
 
 def write_wav(path: str, wav: np.ndarray, sampling_rate: int):

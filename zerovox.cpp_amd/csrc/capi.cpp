@@ -332,6 +332,26 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
     });
 }
 
+zv_status zv_gguf_inspect(const char *gguf_path, uint32_t *n_tensors, uint32_t *max_seq_len, int tensor_index,
+                          char *name_out, uint32_t *type_out, int64_t *ne_out)
+{
+    return guarded([&] {
+        ZV_NEED(gguf_path, "null path");
+        zv::GgufFile g;
+        g.open(gguf_path);
+        if (n_tensors) *n_tensors = (uint32_t)g.tensors().size();
+        if (max_seq_len) *max_seq_len = g.get_u32("zerovox-resnet-fs2-styletts.max_seq_len");
+        if (tensor_index >= 0)
+        {
+            if ((size_t)tensor_index >= g.tensors().size()) zv::fail(ZV_ERR_ARG, "tensor index %d out of range", tensor_index);
+            const zv::GgufTensor &t = g.tensors()[tensor_index];
+            if (name_out) { strncpy(name_out, t.name.c_str(), 63); name_out[63] = 0; }
+            if (type_out) *type_out = t.type;
+            if (ne_out) for (int i = 0; i < 4; i++) ne_out[i] = t.ne[i];
+        }
+    });
+}
+
 // ---- WAV writer (reference src/zerovox.cpp:337-391 uses libsndfile SF_FORMAT_WAV | SF_FORMAT_PCM_16) ----
 
 zv_status zv_write_wav(const char *path, const float *wav, size_t n_samples, uint32_t sampling_rate)
