@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 namespace zv
 {
@@ -71,6 +72,171 @@ void pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int C
 
 __device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : x * s; }
 
+// ---- stage: HBM -> prologue -> f16 -> LDS.  U independent 16-byte loads per thread are issued before any of
+// them is consumed (hipcc otherwise waits vmcnt(0) after every load and the tile fill becomes a chain of
+// full HBM latencies).  LDS row r holds input time row_t0 + r; out-of-range rows are zeros.
+template <int U, int PRO>
+__device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
+                                             int tid)
+{
+    const int cols = ck >> 2;
+    const int total = rows * cols;
+    const int L = J.L;
+    constexpr int pro = PRO;
+    int r = tid / cols, c4 = tid - r * cols;
+    const int dr = 256 / cols, dc = 256 - dr * cols;
+    for (int base = tid; base < total; base += 256 * U)
+    {
+        float4 v[U], v1[U], v2[U];
+        half4 hraw[U];
+        int lofs[U];
+        bool live[U], inr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            live[u] = base + u * 256 < total;
+            const int t = row_t0 + r;
+            inr[u] = live[u] && t >= 0 && t < L;
+            lofs[u] = r * RS + c4 * 8;
+            const size_t off = (size_t)(inr[u] ? t : 0) * J.ldx + c0 + c4 * 4;
+            if constexpr (pro == PRO_RAW_F16)
+                hraw[u] = *(const half4 *)((const _Float16 *)J.x0 + off);
+            else
+            {
+                v[u] = *(const float4 *)((const float *)J.x0 + off);
+                if constexpr (pro == PRO_SUM3_ACT)
+                {
+                    v1[u] = *(const float4 *)((const float *)J.x1 + off);
+                    v2[u] = *(const float4 *)((const float *)J.x2 + off);
+                }
+            }
+            r += dr;
+            c4 += dc;
+            if (c4 >= cols) { c4 -= cols; r++; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            if (!live[u]) continue;
+            half4 h = {0, 0, 0, 0};
+            if (inr[u])
+            {
+                if constexpr (pro == PRO_RAW_F16)
+                    h = hraw[u];
+                else
+                {
+                    float4 x = v[u];
+                    const int c = c0 + ((lofs[u] % RS) >> 1);
+                    (void)c;
+                    if constexpr (pro == PRO_SUM3_ACT)
+                    {
+                        const float sc = J.pscale;
+                        x.x = ((x.x + v1[u].x) + v2[u].x) * sc;
+                        x.y = ((x.y + v1[u].y) + v2[u].y) * sc;
+                        x.z = ((x.z + v1[u].z) + v2[u].z) * sc;
+                        x.w = ((x.w + v1[u].w) + v2[u].w) * sc;
+                    }
+                    else if constexpr (pro == PRO_NORM_ACT)
+                    {
+                        const float4 st0 = *(const float4 *)(J.pstat + 2 * c);       // mean,rstd,mean,rstd
+                        const float4 st1 = *(const float4 *)(J.pstat + 2 * c + 4);
+                        const float4 g = *(const float4 *)(J.pa + c);
+                        const float4 b = *(const float4 *)(J.pb + c);
+                        x.x = ((x.x - st0.x) * st0.y) * g.x + b.x;
+                        x.y = ((x.y - st0.z) * st0.w) * g.y + b.y;
+                        x.z = ((x.z - st1.x) * st1.y) * g.z + b.z;
+                        x.w = ((x.w - st1.z) * st1.w) * g.w + b.w;
+                    }
+                    else if constexpr (pro == PRO_MELNORM)
+                    {
+                        const float4 a = *(const float4 *)(J.pa + c);
+                        const float4 b = *(const float4 *)(J.pb + c);
+                        x.x = (x.x - a.x) / b.x;
+                        x.y = (x.y - a.y) / b.y;
+                        x.z = (x.z - a.z) / b.z;
+                        x.w = (x.w - a.w) / b.w;
+                    }
+                    if constexpr (pro != PRO_MELNORM)
+                    {
+                        const float sl = J.slope;
+                        x.x = lrelu(x.x, sl);
+                        x.y = lrelu(x.y, sl);
+                        x.z = lrelu(x.z, sl);
+                        x.w = lrelu(x.w, sl);
+                    }
+                    h[0] = (_Float16)x.x;      // v_cvt_f16_f32: round-to-nearest-even, like _cvtss_sh(x, 0)
+                    h[1] = (_Float16)x.y;
+                    h[2] = (_Float16)x.z;
+                    h[3] = (_Float16)x.w;
+                }
+            }
+            *(half4 *)(smem + lofs[u]) = h;
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void stage_tile(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
+                                           int tid)
+{
+    switch (J.pro)      // wave-uniform; each case is a straight-line batched fill
+    {
+        case PRO_RAW_F16: stage_tile_p<U, PRO_RAW_F16>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_ACT: stage_tile_p<U, PRO_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_NORM_ACT: stage_tile_p<U, PRO_NORM_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_MELNORM: stage_tile_p<U, PRO_MELNORM>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        default: stage_tile_p<U, PRO_SUM3_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+    }
+}
+
+// ---- compute: S = K * nkc MFMA steps over one staged chunk.  A fragments are double-buffered in registers
+// (the ds_reads of step s+1 are in flight while the MFMAs of step s run), B fragments come from L2 through a
+// 4-deep register ring.
+template <int MT, bool SWAP = false>
+__device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT], const char *abase, int RS, int dil, const half8 *wp,
+                                           int K, int nkc)
+{
+    // Branch-free, 4 steps per iteration with static register slots so that hipcc can count its waits: the B
+    // fragment consumed in slot u was requested four steps earlier (s_waitcnt vmcnt(3)), the A fragments one step
+    // earlier.  Steps S..round_up(S,4)-1 do not exist: they run with B = 0 (adds nothing) on a clamped A address.
+    const int S = K * nkc;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) b[u] = wp[(size_t)((u < S) ? u : S - 1) * 64];
+    half8 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) a[mt] = *(const half8 *)(abase + mt * 32 * RS);
+    int tap = 0, kc = 0;
+    for (int s0 = 0; s0 < S; s0 += 4)
+    {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            if (++kc == nkc) { kc = 0; tap++; }
+            if (tap >= K) tap = 0;                   // past the last step: any valid address
+            const char *ap = abase + tap * dil * RS + kc * 32;
+            half8 an[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) an[mt] = *(const half8 *)(ap + mt * 32 * RS);
+            const half8 bu = (s0 + u < S) ? b[u] : zero8;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+            {
+                // SWAP: weights as the A operand -> D[oc][time] (4 consecutive channels per lane register quad)
+                if constexpr (SWAP)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bu, a[mt], acc[mt], 0, 0, 0);
+                else
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bu, acc[mt], 0, 0, 0);
+            }
+            const int sn = s0 + u + 4;
+            b[u] = wp[(size_t)((sn < S) ? sn : S - 1) * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a[mt] = an[mt];
+        }
+    }
+}
+
 template <int MT, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
@@ -109,129 +275,36 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
-
-        // ---------------- stage: HBM -> prologue -> f16 -> LDS ----------------
-        {
-            const int cols = ck >> 2;
-            int r = tid / cols, c4 = tid - r * cols;
-            const int dr = 256 / cols, dc = 256 - dr * cols;
-            const int pro = J.pro;
-            while (r < rows)
-            {
-                const int t = m0 - J.pad + r;
-                half4 h = {0, 0, 0, 0};
-                if (t >= 0 && t < L)
-                {
-                    const int c = c0 + c4 * 4;
-                    const size_t off = (size_t)t * J.ldx + c;
-                    if (pro == PRO_RAW_F16)
-                    {
-                        h = *(const half4 *)((const _Float16 *)J.x0 + off);
-                    }
-                    else
-                    {
-                        float4 v = *(const float4 *)((const float *)J.x0 + off);
-                        if (pro == PRO_SUM3_ACT)
-                        {
-                            const float4 b = *(const float4 *)((const float *)J.x1 + off);
-                            const float4 d = *(const float4 *)((const float *)J.x2 + off);
-                            const float s = J.pscale;
-                            v.x = ((v.x + b.x) + d.x) * s;
-                            v.y = ((v.y + b.y) + d.y) * s;
-                            v.z = ((v.z + b.z) + d.z) * s;
-                            v.w = ((v.w + b.w) + d.w) * s;
-                        }
-                        else if (pro == PRO_NORM_ACT)
-                        {
-                            const float4 st0 = *(const float4 *)(J.pstat + 2 * c);       // mean,rstd,mean,rstd
-                            const float4 st1 = *(const float4 *)(J.pstat + 2 * c + 4);
-                            const float4 g = *(const float4 *)(J.pa + c);
-                            const float4 b = *(const float4 *)(J.pb + c);
-                            v.x = ((v.x - st0.x) * st0.y) * g.x + b.x;
-                            v.y = ((v.y - st0.z) * st0.w) * g.y + b.y;
-                            v.z = ((v.z - st1.x) * st1.y) * g.z + b.z;
-                            v.w = ((v.w - st1.z) * st1.w) * g.w + b.w;
-                        }
-                        else if (pro == PRO_MELNORM)
-                        {
-                            const float4 a = *(const float4 *)(J.pa + c);
-                            const float4 b = *(const float4 *)(J.pb + c);
-                            v.x = (v.x - a.x) / b.x;
-                            v.y = (v.y - a.y) / b.y;
-                            v.z = (v.z - a.z) / b.z;
-                            v.w = (v.w - a.w) / b.w;
-                        }
-                        if (pro != PRO_MELNORM)
-                        {
-                            const float s = J.slope;
-                            v.x = lrelu(v.x, s);
-                            v.y = lrelu(v.y, s);
-                            v.z = lrelu(v.z, s);
-                            v.w = lrelu(v.w, s);
-                        }
-                        h[0] = (_Float16)v.x;      // v_cvt_f16_f32: round-to-nearest-even, like _cvtss_sh(x, 0)
-                        h[1] = (_Float16)v.y;
-                        h[2] = (_Float16)v.z;
-                        h[3] = (_Float16)v.w;
-                    }
-                }
-                *(half4 *)(smem + r * RS + c4 * 8) = h;
-                r += dr;
-                c4 += dc;
-                if (c4 >= cols) { c4 -= cols; r++; }
-            }
-        }
+        if (!(J.dbg & 1)) stage_tile<4>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         __syncthreads();
-
-        // ---------------- compute: S = K * nkc MFMA steps over this chunk ----------------
-        if (n_ok)
+        if (n_ok && !(J.dbg & 2))
         {
-            const int nkc = ck >> 4;
-            const int S = K * nkc;
             const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
-            half8 bq[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) bq[u] = wp[(size_t)((u < S) ? u : S - 1) * 64];
-            int tap = 0, kc = 0;
-            for (int s0 = 0; s0 < S; s0 += 4)
-            {
-                half8 bn[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                {
-                    const int sn = s0 + 4 + u;
-                    bn[u] = wp[(size_t)((sn < S) ? sn : S - 1) * 64];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                {
-                    if (s0 + u < S)
-                    {
-                        const char *ap = abase + tap * dil * RS + kc * 32;
-#pragma unroll
-                        for (int mt = 0; mt < MT; mt++)
-                        {
-                            const half8 a = *(const half8 *)(ap + mt * 32 * RS);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[u], acc[mt], 0, 0, 0);
-                        }
-                        if (++kc == nkc) { kc = 0; tap++; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) bq[u] = bn[u];
-            }
+            mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
         }
     }
 
     // ---------------- epilogue ----------------
-    if (!n_ok) return;
+    if (!n_ok || (J.dbg & 4)) return;
     const int oc = nt * 32 + (lane & 31);
     if (oc >= Cout_p) return;
     const float bias = J.bias ? J.bias[oc] : 0.f;
     const float escale = J.escale;
     const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
+    const bool has_res = J.res != nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
+    {
+        float resv[16];
+        if (has_res)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
+            {
+                const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                resv[r] = J.res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
@@ -239,7 +312,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
             if (t < L)
             {
                 float v = acc[mt][r] + bias;
-                if (J.res) v = v + J.res[(size_t)t * J.ldres + oc];
+                if (has_res) v = v + resv[r];
                 v = v * escale;
                 if (J.eact) v = lrelu(v, J.oslope);
                 if (J.out_f16)
@@ -248,6 +321,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
                     ((float *)J.out)[(size_t)t * J.ldo + oc] = v;
             }
         }
+    }
 }
 
 template <int MT, int WN>
@@ -272,11 +346,13 @@ static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
 {
     if (njobs < 1 || njobs > CONV_MAX_JOBS) return hipErrorInvalidValue;
+    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
     ConvJobs js;
     int Lmax = 0, Kmax = 0, halo = 0, ck = 0;
     for (int i = 0; i < njobs; i++)
     {
         js.j[i] = jobs[i];
+        js.j[i].dbg = dbg;
         if (jobs[i].Cout_p != jobs[0].Cout_p) return hipErrorInvalidValue;
         Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
         const int h = (jobs[i].K - 1) * jobs[i].dil;
@@ -297,12 +373,195 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
     };
     int MT = 4;
     while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
+    {   // experiment hook: ZV_CONV_MT=<min MT> / ZV_CONV_WGS=<target workgroups per CU * 100>
+        static const char *e_mt = getenv("ZV_CONV_MT");
+        static const char *e_w = getenv("ZV_CONV_WGS");
+        if (e_w)
+        {
+            const long tgt = atol(e_w) * n_cu / 100;
+            MT = 4;
+            while (MT > 1 && wgs(MT) < tgt) MT >>= 1;
+        }
+        if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
+    }
 #define ZV_CASE(mt, wn) \
     if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, Kh, 1, ck);
     ZV_CASE(4, 4) ZV_CASE(2, 4) ZV_CASE(1, 4)
     ZV_CASE(4, 2) ZV_CASE(2, 2) ZV_CASE(1, 2)
     ZV_CASE(4, 1) ZV_CASE(2, 1) ZV_CASE(1, 1)
 #undef ZV_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused dilation pair of a HiFi-GAN residual block (reference src/hifigan.cpp:99-182):
+//     xt = lrelu(conv(lrelu(y), k, dil) + b1);  out = y + (conv(xt, k, 1) + b2)
+// One workgroup produces TM = BM - (k-1) output rows: it stages f16(lrelu(y)) for BM + (k-1)*dil rows, runs
+// conv1 over BM rows (the k-1 extra rows are conv2's halo) with the weights as the MFMA A operand so that a
+// lane ends up with 4 consecutive channels per register quad, packs xt = f16(lrelu(. + b1)) straight back
+// into the same LDS region (rows outside [0, L) are conv2's zero padding), runs conv2 from there and adds
+// bias + residual in the epilogue.  xt never touches HBM.
+template <int MT, int WN>
+__global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
+{
+    constexpr int WM = 4 / WN;
+    constexpr int BM = 32 * MT * WM;
+    const PairJob &P = jobs.j[blockIdx.z];
+    const int L = P.L, K = P.K, dil = P.dil, Cp = P.Cp;
+    const int h2 = (K - 1) / 2, h1 = h2 * dil;
+    const int TM = BM - 2 * h2;
+    const int t0 = blockIdx.x * TM;
+    if (t0 >= L) return;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int RS = Cp * 2 + 16;
+    const int nkc = Cp >> 4;
+
+    // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
+    {
+        ConvJob cj;
+        cj.x0 = P.y;
+        cj.ldx = Cp;
+        cj.L = L;
+        cj.slope = P.slope;
+        if (!(P.dbg & 1)) stage_tile_p<4, PRO_ACT>(cj, smem, RS, 0, Cp, t0 - h2 - h1, BM + 2 * h1, tid);
+    }
+    __syncthreads();
+
+    const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
+    floatx16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
+    if (!(P.dbg & 2))
+        mfma_chunk<MT, true>(acc, abase, RS, dil, (const half8 *)P.w1 + (size_t)wn * K * nkc * 64 + lane, K, nkc);
+    __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
+
+    // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
+    {
+        const int hh = lane >> 5;
+        float4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + wn * 32 + 8 * q + 4 * hh);
+        const float sl = P.slope;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+        {
+            const int i = wm * 32 * MT + mt * 32 + (lane & 31);
+            const int t = t0 - h2 + i;
+            const bool in = t >= 0 && t < L;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                half4 h;
+                h[0] = (_Float16)(in ? lrelu(acc[mt][4 * q + 0] + bq[q].x, sl) : 0.f);
+                h[1] = (_Float16)(in ? lrelu(acc[mt][4 * q + 1] + bq[q].y, sl) : 0.f);
+                h[2] = (_Float16)(in ? lrelu(acc[mt][4 * q + 2] + bq[q].z, sl) : 0.f);
+                h[3] = (_Float16)(in ? lrelu(acc[mt][4 * q + 3] + bq[q].w, sl) : 0.f);
+                *(half4 *)(smem + i * RS + (wn * 32 + 8 * q + 4 * hh) * 2) = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    if (!(P.dbg & 2))
+        mfma_chunk<MT, false>(acc, abase, RS, 1, (const half8 *)P.w2 + (size_t)wn * K * nkc * 64 + lane, K, nkc);
+
+    // ---- epilogue: out = y + (conv2 + b2)
+    if (P.dbg & 4) return;
+    const int oc = wn * 32 + (lane & 31);
+    const float bias = P.b2[oc];
+    const int jbase = wm * 32 * MT + 4 * (lane >> 5);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+    {
+        float resv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int t = t0 + j;
+            resv[r] = P.y[(size_t)((j < TM && t < L) ? t : t0) * Cp + oc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int t = t0 + j;
+            if (j < TM && t < L) P.out[(size_t)t * Cp + oc] = (acc[mt][r] + bias) + resv[r];
+        }
+    }
+}
+
+bool pair_supported(int Cp, int ck) { return (Cp == 32 || Cp == 64 || Cp == 128) && ck == Cp; }
+
+template <int MT, int WN>
+static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax, int Cp)
+{
+    constexpr int BM = 32 * MT * (4 / WN);
+    const int TMmin = BM - (Kmax - 1);
+    if (TMmin < 32) return hipErrorInvalidValue;
+    // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
+    dim3 grid((Lmax + TMmin - 1) / TMmin, 1, njobs);
+    const size_t lds = (size_t)(BM + (Kmax - 1) * dmax) * (Cp * 2 + 16);
+    auto kern = resblock_pair_kernel<MT, WN>;
+    if (lds > 64 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
+{
+    if (njobs < 1 || njobs > PAIR_MAX_JOBS) return hipErrorInvalidValue;
+    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
+    static const int mt_env = getenv("ZV_PAIR_MT") ? atoi(getenv("ZV_PAIR_MT")) : 0;
+    PairJobs js;
+    int Lmax = 0, Kmax = 0, dmax = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        js.j[i] = jobs[i];
+        js.j[i].dbg = dbg;
+        if (jobs[i].Cp != jobs[0].Cp) return hipErrorInvalidValue;
+        Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
+        Kmax = jobs[i].K > Kmax ? jobs[i].K : Kmax;
+        dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
+    }
+    for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
+    const int Cp = jobs[0].Cp;
+    const int WN = Cp / 32;
+    auto wgs = [&](int MT) {
+        const int BM = 32 * MT * (4 / WN);
+        const int TM = BM - (Kmax - 1);
+        return TM < 32 ? 0L : (long)((Lmax + TM - 1) / TM) * njobs;
+    };
+    // tallest tile that still gives every CU about three workgroups, but never a BM so small that the
+    // (k-1)-row halo dominates: BM >= 64 (WN = 4) / 128 (WN = 1, 2)
+    const int mt_floor = 2;
+    int MT = 4;
+    while (MT > mt_floor && wgs(MT) < 3L * n_cu) MT >>= 1;
+    if (mt_env) MT = mt_env;
+#define ZV_PCASE(mt, wn) \
+    if (MT == mt && WN == wn) return launch_pair_cfg<mt, wn>(s, js, njobs, Lmax, Kmax, dmax, Cp);
+    ZV_PCASE(4, 1) ZV_PCASE(2, 1)
+    ZV_PCASE(4, 2) ZV_PCASE(2, 2) ZV_PCASE(1, 2)
+    ZV_PCASE(4, 4) ZV_PCASE(2, 4) ZV_PCASE(1, 4)
+#undef ZV_PCASE
     return hipErrorInvalidValue;
 }
 

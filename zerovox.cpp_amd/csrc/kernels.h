@@ -55,6 +55,7 @@ struct ConvJob
     int          out_f16;
     void        *out;
     int          ldo;
+    int          dbg;            // timing-only ablation bits (ZV_DBG env): 1 no staging loads, 2 no MFMA, 4 no epilogue
 };
 
 constexpr int CONV_MAX_JOBS = 4;
@@ -70,6 +71,29 @@ int    conv_pick_ck(int Cin_p);
 void   pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, int ck, uint16_t *dst);
 // all jobs of one launch share L-extent class, Cout_p and tile configuration
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu);
+
+// ---- fused HiFi-GAN dilation pair (reference src/hifigan.cpp:99-182, one loop iteration):
+//   out = y + ( conv(lrelu(conv(lrelu(y), k, dil) + b1), k, 1) + b2 )
+// in ONE launch: xt never leaves LDS, y is read once (+ halo) and written once -> 8 B/element of HBM traffic
+// instead of the 20 B/element the two separate convs are accounted for algorithmically.
+struct PairJob
+{
+    const float *y;          // [L][Cp] f32
+    float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
+    const void  *w1, *w2;    // packed like ConvJob::w (single cin chunk: ck == Cp)
+    const float *b1, *b2;
+    int          L, Cp, K, dil;
+    float        slope;
+    int          dbg;
+};
+constexpr int PAIR_MAX_JOBS = 3;
+struct PairJobs
+{
+    PairJob j[PAIR_MAX_JOBS];
+};
+// true when (Cp, K, dil) can run on the fused kernel (Cp in {32, 64, 128}, weights packed with ck == Cp)
+bool       pair_supported(int Cp, int ck);
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu);
 
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
 struct OutConvArgs

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace zv
@@ -141,6 +142,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     ZV_HIP(hipGetDeviceProperties(&prop, dev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) fail(ZV_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
     n_cu = prop.multiProcessorCount;
+    no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
     GgufFile g;
@@ -448,7 +450,7 @@ size_t Model::arena_bytes_for(uint32_t N, uint32_t T) const
         L *= hp.voc_upsample_scales[i];
         C >>= 1;
         const size_t Cp = round_up(C, 16);
-        const size_t need = L * Cp * (4 + 3 * 4 + 3 * 2) + 16 * 256;
+        const size_t need = L * Cp * (4 + 3 * 4 + 3 * 4) + 16 * 256;
         pool[i & 1] = std::max(pool[i & 1], need);
     }
     voc += pool[0] + pool[1] + 4096;
@@ -588,7 +590,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         {
             Ls *= voc_.scales[i];
             Cs >>= 1;
-            const size_t need = Ls * round_up(Cs, 16) * (4 + 3 * 4 + 3 * 2) + 16 * 256;
+            const size_t need = Ls * round_up(Cs, 16) * (4 + 3 * 4 + 3 * 4) + 16 * 256;
             pool_sz[i & 1] = std::max(pool_sz[i & 1], need);
         }
         pool_base[0] = (char *)arena_.take(pool_sz[0]);
@@ -610,7 +612,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         float *y[3];
         _Float16 *xt[3];
         for (int j = 0; j < 3; j++) y[j] = pool.take_n<float>((size_t)Lo * Cp);
-        for (int j = 0; j < 3; j++) xt[j] = pool.take_n<_Float16>((size_t)Lo * Cp);
+        for (int j = 0; j < 3; j++) xt[j] = (_Float16 *)pool.take_n<float>((size_t)Lo * Cp);   // f16 xt, or f32 ping-pong partner of y (fused path)
 
         // V1: leaky_relu(0.1) -> transposed conv (polyphase) + bias      (src/hifigan.cpp:281-297, 22-71)
         {
@@ -626,15 +628,23 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         L = Lo;
         C = Cout;
 
-        // V2: the 3 MRF branches run side by side (one job each); per dilation two launches
+        // V2: the 3 MRF branches run side by side (one job each).  Fused path: one launch per dilation
+        // (conv -> lrelu -> conv -> + residual, xt kept in LDS), y ping-pongs between two buffers because a
+        // workgroup's halo rows belong to its neighbours' output tiles.
+        const ResPair &rp0 = voc_.pairs[((size_t)i * voc_.n_rb) * voc_.n_dil];
+        const bool fused = !no_fuse_ && pair_supported(Cp, rp0.c1.ck) && pair_supported(Cp, rp0.c2.ck);
+        const float *ycur[3] = {ub, ub, ub};
         for (int d = 0; d < voc_.n_dil; d++)
         {
             ConvJob j1[3], j2[3];
+            PairJob pj[3];
             double b1 = 0, f1 = 0, b2 = 0, f2 = 0;
             for (int jb = 0; jb < 3; jb++)
             {
                 const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
-                const float *yin = (d == 0) ? ub : y[jb];
+                const float *yin = ycur[jb];
+                float *yout = fused ? ((d & 1) ? (float *)xt[jb] : y[jb]) : y[jb];
+                if (fused && rp.c1.K != rp.c2.K) fail(ZV_ERR_SHAPE, "residual block %d: convs1/convs2 kernel sizes differ", i * voc_.n_rb + jb);
                 // xt = lrelu(conv(lrelu(y), k, dil) + b)  kept as the f16 operand of the next conv (:108-150)
                 ConvJob a = job(rp.c1, L);
                 a.x0 = yin;
@@ -655,14 +665,34 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 b.ldres = Cp;
                 b.out = y[jb];
                 j2[jb] = b;
+                PairJob &p = pj[jb];
+                memset(&p, 0, sizeof(p));
+                p.y = yin;
+                p.out = yout;
+                p.w1 = rp.c1.w;
+                p.w2 = rp.c2.w;
+                p.b1 = rp.c1.bias;
+                p.b2 = rp.c2.bias;
+                p.L = L;
+                p.Cp = Cp;
+                p.K = rp.c1.K;
+                p.dil = voc_.dil[d];
+                p.slope = 0.1f;
+                ycur[jb] = fused ? yout : y[jb];
                 b1 += conv_bytes(L, C, C, rp.c1.K, false);
                 f1 += conv_flops(L, C, C, rp.c1.K);
                 b2 += conv_bytes(L, C, C, rp.c2.K, true);
                 f2 += conv_flops(L, C, C, rp.c2.K);
             }
-            conv(j1, 3, "voc_resblock_conv", b1, f1);
-            conv(j2, 3, "voc_resblock_conv", b2, f2);
+            if (fused)
+                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu));
+            else
+            {
+                conv(j1, 3, "voc_resblock_conv", b1, f1);
+                conv(j2, 3, "voc_resblock_conv", b2, f2);
+            }
         }
+        for (int jb = 0; jb < 3; jb++) y[jb] = const_cast<float *>(ycur[jb]);
         for (int jb = 0; jb < 3; jb++) prev_y[jb] = y[jb];
     }
 

@@ -170,6 +170,7 @@ class Model
     void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
     void tock(hipEvent_t e0, const char *name, double bytes, double flops);
 
+    bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     std::vector<VocoderGraph> graphs_;
     void drop_graphs();
 };
