@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzerovox_amd.so")
+LIB_PATH = os.environ.get("ZEROVOX_AMD_LIB") or os.path.join(HERE, "libzerovox_amd.so")   # env override: A/B builds
 
 # every symbol include/zerovox_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -22,6 +22,7 @@
 
 #include <hip/hip_fp16.h>
 #include <cstdlib>
+#include <cstring>
 
 namespace zv
 {
@@ -31,6 +32,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 static constexpr int CK_MAX = 128;
+#ifndef ZV_STAGE_U
+#define ZV_STAGE_U 4
+#endif
 
 int conv_pick_ck(int Cin_p)
 {
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
-        if (!(J.dbg & 1)) stage_tile<4>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         __syncthreads();
         if (n_ok && !(J.dbg & 2))
         {
@@ -401,13 +405,118 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
 // lane ends up with 4 consecutive channels per register quad, packs xt = f16(lrelu(. + b1)) straight back
 // into the same LDS region (rows outside [0, L) are conv2's zero padding), runs conv2 from there and adds
 // bias + residual in the epilogue.  xt never touches HBM.
-template <int MT, int WN>
+//
+// The MFMA loop is specialised on the channel count so that every LDS / weight address inside an iteration is
+// an immediate: one body = 8 steps = 8 / (CP/16) taps, the per-body bookkeeping is a handful of vector adds.  The first version of this loop carried ~15 scalar/vector instructions of
+// tap/channel bookkeeping per MFMA and was instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 74 % of the kernel with
+// the MFMA pipe 19 % busy, profiles/r01_v2_pmc.txt).  Weights for this path are packed per 32-channel output
+// tile as round_up(K*CP/16, 4) + 8 blocks, zero blocks behind the real ones: the loop needs no tail handling
+// and its prefetch never leaves the tile's segment.
+size_t pair_weight_halfs(int Cp, int K)
+{
+    const int nkc = Cp / 16;
+    return (size_t)(Cp / 32) * (round_up(K * nkc, 4) + 8) * 512;
+}
+
+void pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
+{
+    const int nkc = Cp / 16;
+    const size_t seg = (size_t)(round_up(K * nkc, 4) + 8) * 512;
+    memset(dst, 0, pair_weight_halfs(Cp, K) * 2);
+    for (int nt = 0; nt < Cp / 32; nt++)
+        for (int tap = 0; tap < K; tap++)
+            for (int kc = 0; kc < nkc; kc++)
+            {
+                uint16_t *d = dst + nt * seg + (size_t)(tap * nkc + kc) * 512;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                    {
+                        const int oc = nt * 32 + (lane & 31), ic = kc * 16 + 8 * (lane >> 5) + j;
+                        d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                    }
+            }
+}
+
+template <int MT, bool SWAP>
+__device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT], const half8 (&a)[MT], const half8 &b)
+{
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+    {
+        if constexpr (SWAP)      // weights as the A operand -> D[oc][time]
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a[mt], acc[mt], 0, 0, 0);
+        else
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b, acc[mt], 0, 0, 0);
+    }
+}
+
+// One body = 8 MFMA steps = 8 / (CP/16) taps.  Two static B register sets ping-pong (b0: steps 0-3, b1: steps 4-7),
+// each refilled for the next body right after its last use; A fragments ping-pong one step ahead.  All LDS and
+// weight addresses inside a body are immediates off (ap + tap * dilRS) and wq.
+template <int CP, int MT, bool SWAP>
+__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT], const char *ap, int dilRS, const half8 *wq, int K)
+{
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    constexpr int TPB = 8 / NKC;                 // taps per body: 4 / 2 / 1 for CP = 32 / 64 / 128
+    const int nsb = (K * NKC + 3) >> 2;          // 4-step sub-blocks (the last one may run partly on zero weights)
+    const int nb = nsb >> 1;
+    half8 b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) b0[u] = wq[u * 64];
+    wq += 4 * 64;
+    half8 a0[MT], a1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) a0[mt] = *(const half8 *)(ap + mt * 32 * RS);
+
+#define ZV_A_ADDR(un) ((un) == 8 ? ap + TPB * dilRS : tb[((un) / NKC) % TPB] + ((un) % NKC) * 32)
+#define ZV_LOAD_A(dst, un)                                                                   \
+    {                                                                                        \
+        const char *np_ = ZV_A_ADDR(un);                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) dst[mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+    }
+    for (int ib = 0; ib < nb; ib++)
+    {
+        const char *tb[4];
+        tb[0] = ap;
+#pragma unroll
+        for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
+#pragma unroll
+        for (int u = 0; u < 4; u++) b1[u] = wq[u * 64];                  // steps 4..7 of this body
+        __builtin_amdgcn_sched_barrier(0);      // keep the four requests here: hipcc otherwise sinks them next to their use
+        ZV_LOAD_A(a1, 1) mfma_step<MT, SWAP>(acc, a0, b0[0]);
+        ZV_LOAD_A(a0, 2) mfma_step<MT, SWAP>(acc, a1, b0[1]);
+        ZV_LOAD_A(a1, 3) mfma_step<MT, SWAP>(acc, a0, b0[2]);
+        ZV_LOAD_A(a0, 4) mfma_step<MT, SWAP>(acc, a1, b0[3]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) b0[u] = wq[(4 + u) * 64];            // steps 0..3 of the next body
+        __builtin_amdgcn_sched_barrier(0);
+        ZV_LOAD_A(a1, 5) mfma_step<MT, SWAP>(acc, a0, b1[0]);
+        ZV_LOAD_A(a0, 6) mfma_step<MT, SWAP>(acc, a1, b1[1]);
+        ZV_LOAD_A(a1, 7) mfma_step<MT, SWAP>(acc, a0, b1[2]);
+        ZV_LOAD_A(a0, 8) mfma_step<MT, SWAP>(acc, a1, b1[3]);
+        ap += TPB * dilRS;
+        wq += 8 * 64;
+    }
+    if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
+    {
+        const char *tb[4] = {ap, ap, ap, ap};
+        ZV_LOAD_A(a1, 1) mfma_step<MT, SWAP>(acc, a0, b0[0]);
+        ZV_LOAD_A(a0, 2) mfma_step<MT, SWAP>(acc, a1, b0[1]);
+        ZV_LOAD_A(a1, 3) mfma_step<MT, SWAP>(acc, a0, b0[2]);
+        mfma_step<MT, SWAP>(acc, a1, b0[3]);
+    }
+#undef ZV_LOAD_A
+#undef ZV_A_ADDR
+}
+
+template <int CP, int MT>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 {
-    constexpr int WM = 4 / WN;
+    constexpr int WN = CP / 32, WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     const PairJob &P = jobs.j[blockIdx.z];
-    const int L = P.L, K = P.K, dil = P.dil, Cp = P.Cp;
+    const int L = P.L, K = P.K, dil = P.dil;
     const int h2 = (K - 1) / 2, h1 = h2 * dil;
     const int TM = BM - 2 * h2;
     const int t0 = blockIdx.x * TM;
@@ -418,17 +527,16 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int RS = Cp * 2 + 16;
-    const int nkc = Cp >> 4;
+    const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;        // half8 units per n-tile segment
 
-    // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
+    // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
     {
         ConvJob cj;
         cj.x0 = P.y;
-        cj.ldx = Cp;
+        cj.ldx = CP;
         cj.L = L;
         cj.slope = P.slope;
-        if (!(P.dbg & 1)) stage_tile_p<4, PRO_ACT>(cj, smem, RS, 0, Cp, t0 - h2 - h1, BM + 2 * h1, tid);
+        if (!(P.dbg & 1)) stage_tile_p<ZV_STAGE_U, PRO_ACT>(cj, smem, RS, 0, CP, t0 - h2 - h1, BM + 2 * h1 + dil, tid);
     }
     __syncthreads();
 
@@ -440,8 +548,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
-    if (!(P.dbg & 2))
-        mfma_chunk<MT, true>(acc, abase, RS, dil, (const half8 *)P.w1 + (size_t)wn * K * nkc * 64 + lane, K, nkc);
+    if (!(P.dbg & 2)) mfma_taps<CP, MT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * wseg + lane, K);
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
 
     // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
@@ -456,15 +563,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         {
             const int i = wm * 32 * MT + mt * 32 + (lane & 31);
             const int t = t0 - h2 + i;
-            const bool in = t >= 0 && t < L;
+            const float keep = (t >= 0 && t < L) ? 1.f : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; q++)
             {
                 half4 h;
-                h[0] = (_Float16)(in ? lrelu(acc[mt][4 * q + 0] + bq[q].x, sl) : 0.f);
-                h[1] = (_Float16)(in ? lrelu(acc[mt][4 * q + 1] + bq[q].y, sl) : 0.f);
-                h[2] = (_Float16)(in ? lrelu(acc[mt][4 * q + 2] + bq[q].z, sl) : 0.f);
-                h[3] = (_Float16)(in ? lrelu(acc[mt][4 * q + 3] + bq[q].w, sl) : 0.f);
+                h[0] = (_Float16)(lrelu(acc[mt][4 * q + 0] + bq[q].x, sl) * keep);
+                h[1] = (_Float16)(lrelu(acc[mt][4 * q + 1] + bq[q].y, sl) * keep);
+                h[2] = (_Float16)(lrelu(acc[mt][4 * q + 2] + bq[q].z, sl) * keep);
+                h[3] = (_Float16)(lrelu(acc[mt][4 * q + 3] + bq[q].w, sl) * keep);
                 *(half4 *)(smem + i * RS + (wn * 32 + 8 * q + 4 * hh) * 2) = h;
             }
         }
@@ -476,14 +583,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     for (int i = 0; i < MT; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-    if (!(P.dbg & 2))
-        mfma_chunk<MT, false>(acc, abase, RS, 1, (const half8 *)P.w2 + (size_t)wn * K * nkc * 64 + lane, K, nkc);
+    if (!(P.dbg & 2)) mfma_taps<CP, MT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * wseg + lane, K);
 
     // ---- epilogue: out = y + (conv2 + b2)
     if (P.dbg & 4) return;
     const int oc = wn * 32 + (lane & 31);
     const float bias = P.b2[oc];
     const int jbase = wm * 32 * MT + 4 * (lane >> 5);
+    const float *yp = P.y + (size_t)t0 * CP + oc;
+    float *op = P.out + (size_t)t0 * CP + oc;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
     {
@@ -492,31 +600,30 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         for (int r = 0; r < 16; r++)
         {
             const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            const int t = t0 + j;
-            resv[r] = P.y[(size_t)((j < TM && t < L) ? t : t0) * Cp + oc];
+            resv[r] = yp[(j < TM && t0 + j < L) ? j * CP : 0];
         }
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
             const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            const int t = t0 + j;
-            if (j < TM && t < L) P.out[(size_t)t * Cp + oc] = (acc[mt][r] + bias) + resv[r];
+            if (j < TM && t0 + j < L) op[j * CP] = (acc[mt][r] + bias) + resv[r];
         }
     }
 }
 
-bool pair_supported(int Cp, int ck) { return (Cp == 32 || Cp == 64 || Cp == 128) && ck == Cp; }
+bool pair_supported(int Cp) { return Cp == 32 || Cp == 64 || Cp == 128; }
 
-template <int MT, int WN>
-static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax, int Cp)
+template <int CP, int MT>
+static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
 {
-    constexpr int BM = 32 * MT * (4 / WN);
+    constexpr int BM = 32 * MT * (4 / (CP / 32));
     const int TMmin = BM - (Kmax - 1);
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
     dim3 grid((Lmax + TMmin - 1) / TMmin, 1, njobs);
-    const size_t lds = (size_t)(BM + (Kmax - 1) * dmax) * (Cp * 2 + 16);
-    auto kern = resblock_pair_kernel<MT, WN>;
+    // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil
+    const size_t lds = (size_t)(BM + (Kmax + 4) * dmax) * (CP * 2 + 16);
+    auto kern = resblock_pair_kernel<CP, MT>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -551,16 +658,15 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
         return TM < 32 ? 0L : (long)((Lmax + TM - 1) / TM) * njobs;
     };
     // tallest tile that still gives every CU about three workgroups, but never a BM so small that the
-    // (k-1)-row halo dominates: BM >= 64 (WN = 4) / 128 (WN = 1, 2)
-    const int mt_floor = 2;
-    int MT = 4;
-    while (MT > mt_floor && wgs(MT) < 3L * n_cu) MT >>= 1;
-    if (mt_env) MT = mt_env;
-#define ZV_PCASE(mt, wn) \
-    if (MT == mt && WN == wn) return launch_pair_cfg<mt, wn>(s, js, njobs, Lmax, Kmax, dmax, Cp);
-    ZV_PCASE(4, 1) ZV_PCASE(2, 1)
-    ZV_PCASE(4, 2) ZV_PCASE(2, 2) ZV_PCASE(1, 2)
-    ZV_PCASE(4, 4) ZV_PCASE(2, 4) ZV_PCASE(1, 4)
+    // (k-1)-row halo dominates (MT >= 2: BM >= 64 / 128 / 256 for 128 / 64 / 32 channels)
+    // measured (512 frames, batch 1): BM = 64/128/256 rows (MT = 2) beats MT = 4 at every channel count — three
+    // to four workgroups per CU hide the staging / epilogue phases better than taller tiles save weight traffic
+    int MT = 2;
+    (void)wgs;
+    if (mt_env == 2 || mt_env == 4) MT = mt_env;
+#define ZV_PCASE(cp, mt) \
+    if (Cp == cp && MT == mt) return launch_pair_cfg<cp, mt>(s, js, njobs, Lmax, Kmax, dmax);
+    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2)
 #undef ZV_PCASE
     return hipErrorInvalidValue;
 }

@@ -80,7 +80,7 @@ struct PairJob
 {
     const float *y;          // [L][Cp] f32
     float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
-    const void  *w1, *w2;    // packed like ConvJob::w (single cin chunk: ck == Cp)
+    const void  *w1, *w2;    // packed by pack_pair_weight (zero-padded per-tile segments)
     const float *b1, *b2;
     int          L, Cp, K, dil;
     float        slope;
@@ -91,8 +91,11 @@ struct PairJobs
 {
     PairJob j[PAIR_MAX_JOBS];
 };
-// true when (Cp, K, dil) can run on the fused kernel (Cp in {32, 64, 128}, weights packed with ck == Cp)
-bool       pair_supported(int Cp, int ck);
+// true when a ResBlock with Cp (padded) channels can run on the fused kernel
+bool       pair_supported(int Cp);
+size_t     pair_weight_halfs(int Cp, int K);
+// GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
+void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu);
 
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------

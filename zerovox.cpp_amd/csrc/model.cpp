@@ -226,6 +226,19 @@ Model::Model(const std::string &path, int dev) : device(dev)
                 snprintf(nb, sizeof(nb), "_meldec.blocks.%d.convs2.%d.1.b", n, d);
                 rp.c2 = load_conv(g, nm, nb, C);
                 if (rp.c1.Cout != C || rp.c2.Cout != C) fail(ZV_ERR_SHAPE, "residual block %d: channel mismatch", n);
+                if (pair_supported(rp.c1.Cout_p) && rp.c1.K == rp.c2.K)
+                {
+                    std::vector<uint16_t> pk(pair_weight_halfs(rp.c1.Cout_p, rp.c1.K));
+                    void **dst[2] = {&rp.p1, &rp.p2};
+                    const char *fmt[2] = {"_meldec.blocks.%d.convs1.%d.1.w", "_meldec.blocks.%d.convs2.%d.1.w"};
+                    for (int q = 0; q < 2; q++)
+                    {
+                        snprintf(nm, sizeof(nm), fmt[q], n, d);
+                        pack_pair_weight((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, pk.data());
+                        *dst[q] = dev_alloc(pk.size() * 2 + 8192);
+                        ZV_HIP(hipMemcpy(*dst[q], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+                    }
+                }
                 if (i == 0 && d == 0) hp.voc_resblock_kernels[j] = rp.c1.K;
                 voc_.pairs.push_back(rp);
             }
@@ -632,7 +645,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         // (conv -> lrelu -> conv -> + residual, xt kept in LDS), y ping-pongs between two buffers because a
         // workgroup's halo rows belong to its neighbours' output tiles.
         const ResPair &rp0 = voc_.pairs[((size_t)i * voc_.n_rb) * voc_.n_dil];
-        const bool fused = !no_fuse_ && pair_supported(Cp, rp0.c1.ck) && pair_supported(Cp, rp0.c2.ck);
+        const bool fused = !no_fuse_ && rp0.p1 != nullptr;
         const float *ycur[3] = {ub, ub, ub};
         for (int d = 0; d < voc_.n_dil; d++)
         {
@@ -644,7 +657,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
                 const float *yin = ycur[jb];
                 float *yout = fused ? ((d & 1) ? (float *)xt[jb] : y[jb]) : y[jb];
-                if (fused && rp.c1.K != rp.c2.K) fail(ZV_ERR_SHAPE, "residual block %d: convs1/convs2 kernel sizes differ", i * voc_.n_rb + jb);
+                if (fused && !rp.p1) fail(ZV_ERR_SHAPE, "residual block %d: branches of one stage must all be fusable", i * voc_.n_rb + jb);
                 // xt = lrelu(conv(lrelu(y), k, dil) + b)  kept as the f16 operand of the next conv (:108-150)
                 ConvJob a = job(rp.c1, L);
                 a.x0 = yin;
@@ -669,8 +682,8 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 memset(&p, 0, sizeof(p));
                 p.y = yin;
                 p.out = yout;
-                p.w1 = rp.c1.w;
-                p.w2 = rp.c2.w;
+                p.w1 = rp.p1;
+                p.w2 = rp.p2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
                 p.L = L;
