@@ -38,9 +38,8 @@ static constexpr int CK_MAX = 128;
 
 int conv_pick_ck(int Cin_p)
 {
-    int nchunks = (Cin_p + CK_MAX - 1) / CK_MAX;
-    int ck = round_up((Cin_p + nchunks - 1) / nchunks, 16);
-    return ck;
+    // full 128-channel chunks (they run on the immediate-address MFMA loop) + one remainder chunk
+    return Cin_p < CK_MAX ? Cin_p : CK_MAX;
 }
 
 size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K)
@@ -241,202 +240,6 @@ __device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT], const char *abas
     }
 }
 
-template <int MT, int WN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
-{
-    constexpr int WM = 4 / WN;
-    constexpr int BM = 32 * MT * WM;
-    const ConvJob &J = jobs.j[blockIdx.z];
-
-    const int L = J.L;
-    const int m0 = blockIdx.x * BM;
-    if (m0 >= L) return;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
-    const int nicb = Cin_p >> 4;
-    const int ntiles = (Cout_p + 31) >> 5;
-    const int nt = blockIdx.y * WN + wn;
-    const bool n_ok = nt < ntiles;
-    const int rows = BM + (K - 1) * dil;
-    const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
-
-    floatx16 acc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-    const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-
-    for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
-    {
-        const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-        if (c0) __syncthreads();
-        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
-        __syncthreads();
-        if (n_ok && !(J.dbg & 2))
-        {
-            const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
-            mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
-        }
-    }
-
-    // ---------------- epilogue ----------------
-    if (!n_ok || (J.dbg & 4)) return;
-    const int oc = nt * 32 + (lane & 31);
-    if (oc >= Cout_p) return;
-    const float bias = J.bias ? J.bias[oc] : 0.f;
-    const float escale = J.escale;
-    const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
-    const bool has_res = J.res != nullptr;
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-    {
-        float resv[16];
-        if (has_res)
-        {
-#pragma unroll
-            for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
-            {
-                const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                resv[r] = J.res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            if (t < L)
-            {
-                float v = acc[mt][r] + bias;
-                if (has_res) v = v + resv[r];
-                v = v * escale;
-                if (J.eact) v = lrelu(v, J.oslope);
-                if (J.out_f16)
-                    ((_Float16 *)J.out)[(size_t)t * J.ldo + oc] = (_Float16)v;
-                else
-                    ((float *)J.out)[(size_t)t * J.ldo + oc] = v;
-            }
-        }
-    }
-}
-
-template <int MT, int WN>
-static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int K, int dil, int ck)
-{
-    constexpr int WM = 4 / WN;
-    constexpr int BM = 32 * MT * WM;
-    const int ntiles = (Cout_p + 31) / 32;
-    dim3 grid((Lmax + BM - 1) / BM, (ntiles + WN - 1) / WN, njobs);
-    const size_t lds = (size_t)(BM + (K - 1) * dil) * (ck * 2 + 16);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_mfma_kernel<MT, WN>;
-    if (lds > 64 * 1024)
-    {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, jobs);
-    return hipGetLastError();
-}
-
-hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
-{
-    if (njobs < 1 || njobs > CONV_MAX_JOBS) return hipErrorInvalidValue;
-    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
-    ConvJobs js;
-    int Lmax = 0, Kmax = 0, halo = 0, ck = 0;
-    for (int i = 0; i < njobs; i++)
-    {
-        js.j[i] = jobs[i];
-        js.j[i].dbg = dbg;
-        if (jobs[i].Cout_p != jobs[0].Cout_p) return hipErrorInvalidValue;
-        Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
-        const int h = (jobs[i].K - 1) * jobs[i].dil;
-        if (h > halo) { halo = h; Kmax = jobs[i].K; }
-        ck = jobs[i].ck > ck ? jobs[i].ck : ck;
-    }
-    for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = jobs[0];
-    // launch_cfg sizes LDS from (K-1)*dil: pass the job with the largest halo as (K, dil) = (halo+1, 1)
-    (void)Kmax;
-    const int Kh = halo + 1;
-    const int Cout_p = jobs[0].Cout_p;
-    const int ntiles = (Cout_p + 31) / 32;
-    const int WN = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
-    // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups
-    auto wgs = [&](int MT) {
-        const int BM = 32 * MT * (4 / WN);
-        return (long)((Lmax + BM - 1) / BM) * ((ntiles + WN - 1) / WN) * njobs;
-    };
-    int MT = 4;
-    while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
-    {   // experiment hook: ZV_CONV_MT=<min MT> / ZV_CONV_WGS=<target workgroups per CU * 100>
-        static const char *e_mt = getenv("ZV_CONV_MT");
-        static const char *e_w = getenv("ZV_CONV_WGS");
-        if (e_w)
-        {
-            const long tgt = atol(e_w) * n_cu / 100;
-            MT = 4;
-            while (MT > 1 && wgs(MT) < tgt) MT >>= 1;
-        }
-        if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
-    }
-#define ZV_CASE(mt, wn) \
-    if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, Kh, 1, ck);
-    ZV_CASE(4, 4) ZV_CASE(2, 4) ZV_CASE(1, 4)
-    ZV_CASE(4, 2) ZV_CASE(2, 2) ZV_CASE(1, 2)
-    ZV_CASE(4, 1) ZV_CASE(2, 1) ZV_CASE(1, 1)
-#undef ZV_CASE
-    return hipErrorInvalidValue;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Fused dilation pair of a HiFi-GAN residual block (reference src/hifigan.cpp:99-182):
-//     xt = lrelu(conv(lrelu(y), k, dil) + b1);  out = y + (conv(xt, k, 1) + b2)
-// One workgroup produces TM = BM - (k-1) output rows: it stages f16(lrelu(y)) for BM + (k-1)*dil rows, runs
-// conv1 over BM rows (the k-1 extra rows are conv2's halo) with the weights as the MFMA A operand so that a
-// lane ends up with 4 consecutive channels per register quad, packs xt = f16(lrelu(. + b1)) straight back
-// into the same LDS region (rows outside [0, L) are conv2's zero padding), runs conv2 from there and adds
-// bias + residual in the epilogue.  xt never touches HBM.
-//
-// The MFMA loop is specialised on the channel count so that every LDS / weight address inside an iteration is
-// an immediate: one body = 8 steps = 8 / (CP/16) taps, the per-body bookkeeping is a handful of vector adds.  The first version of this loop carried ~15 scalar/vector instructions of
-// tap/channel bookkeeping per MFMA and was instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 74 % of the kernel with
-// the MFMA pipe 19 % busy, profiles/r01_v2_pmc.txt).  Weights for this path are packed per 32-channel output
-// tile as round_up(K*CP/16, 4) + 8 blocks, zero blocks behind the real ones: the loop needs no tail handling
-// and its prefetch never leaves the tile's segment.
-size_t pair_weight_halfs(int Cp, int K)
-{
-    const int nkc = Cp / 16;
-    return (size_t)(Cp / 32) * (round_up(K * nkc, 4) + 8) * 512;
-}
-
-void pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
-{
-    const int nkc = Cp / 16;
-    const size_t seg = (size_t)(round_up(K * nkc, 4) + 8) * 512;
-    memset(dst, 0, pair_weight_halfs(Cp, K) * 2);
-    for (int nt = 0; nt < Cp / 32; nt++)
-        for (int tap = 0; tap < K; tap++)
-            for (int kc = 0; kc < nkc; kc++)
-            {
-                uint16_t *d = dst + nt * seg + (size_t)(tap * nkc + kc) * 512;
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++)
-                    {
-                        const int oc = nt * 32 + (lane & 31), ic = kc * 16 + 8 * (lane >> 5) + j;
-                        d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
-                    }
-            }
-}
-
 template <int MT, bool SWAP>
 __device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT], const half8 (&a)[MT], const half8 &b)
 {
@@ -507,6 +310,210 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT], const char *ap, i
     }
 #undef ZV_LOAD_A
 #undef ZV_A_ADDR
+}
+
+template <int MT, int WN>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
+{
+    constexpr int WM = 4 / WN;
+    constexpr int BM = 32 * MT * WM;
+    const ConvJob &J = jobs.j[blockIdx.z];
+
+    const int L = J.L;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= L) return;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
+    const int nicb = Cin_p >> 4;
+    const int ntiles = (Cout_p + 31) >> 5;
+    const int nt = blockIdx.y * WN + wn;
+    const bool n_ok = nt < ntiles;
+    const int rows = BM + (K - 1) * dil;
+    const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
+
+    floatx16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
+
+    for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
+    {
+        const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
+        if (c0) __syncthreads();
+        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        __syncthreads();
+        if (n_ok && !(J.dbg & 2))
+        {
+            const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
+            // full chunks of 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there and
+            // the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
+            if (ck == 128 && J.ck == 128)
+                mfma_taps<128, MT, false>(acc, abase, dil * RS, wp, K);
+            else if (ck == 64 && J.ck == 64)
+                mfma_taps<64, MT, false>(acc, abase, dil * RS, wp, K);
+            else
+                mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    if (!n_ok || (J.dbg & 4)) return;
+    const int oc = nt * 32 + (lane & 31);
+    if (oc >= Cout_p) return;
+    const float bias = J.bias ? J.bias[oc] : 0.f;
+    const float escale = J.escale;
+    const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
+    const bool has_res = J.res != nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+    {
+        float resv[16];
+        if (has_res)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
+            {
+                const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                resv[r] = J.res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+            if (t < L)
+            {
+                float v = acc[mt][r] + bias;
+                if (has_res) v = v + resv[r];
+                v = v * escale;
+                if (J.eact) v = lrelu(v, J.oslope);
+                if (J.out_f16)
+                    ((_Float16 *)J.out)[(size_t)t * J.ldo + oc] = (_Float16)v;
+                else
+                    ((float *)J.out)[(size_t)t * J.ldo + oc] = v;
+            }
+        }
+    }
+}
+
+template <int MT, int WN>
+static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int K, int dil, int ck, int dmax_)
+{
+    constexpr int WM = 4 / WN;
+    constexpr int BM = 32 * MT * WM;
+    const int ntiles = (Cout_p + 31) / 32;
+    dim3 grid((Lmax + BM - 1) / BM, (ntiles + WN - 1) / WN, njobs);
+    const size_t lds = (size_t)(BM + (K - 1) * dil + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = conv1d_mfma_kernel<MT, WN>;
+    if (lds > 64 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, jobs);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
+{
+    if (njobs < 1 || njobs > CONV_MAX_JOBS) return hipErrorInvalidValue;
+    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
+    ConvJobs js;
+    int Lmax = 0, Kmax = 0, halo = 0, ck = 0, dmax = 1;
+    for (int i = 0; i < njobs; i++)
+    {
+        js.j[i] = jobs[i];
+        dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
+        js.j[i].dbg = dbg;
+        if (jobs[i].Cout_p != jobs[0].Cout_p) return hipErrorInvalidValue;
+        Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
+        const int h = (jobs[i].K - 1) * jobs[i].dil;
+        if (h > halo) { halo = h; Kmax = jobs[i].K; }
+        ck = jobs[i].ck > ck ? jobs[i].ck : ck;
+    }
+    for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = jobs[0];
+    // launch_cfg sizes LDS from (K-1)*dil: pass the job with the largest halo as (K, dil) = (halo+1, 1)
+    (void)Kmax;
+    const int Kh = halo + 1;
+    const int Cout_p = jobs[0].Cout_p;
+    const int ntiles = (Cout_p + 31) / 32;
+    const int WN = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+    // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups
+    auto wgs = [&](int MT) {
+        const int BM = 32 * MT * (4 / WN);
+        return (long)((Lmax + BM - 1) / BM) * ((ntiles + WN - 1) / WN) * njobs;
+    };
+    int MT = 4;
+    while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
+    {   // experiment hook: ZV_CONV_MT=<min MT> / ZV_CONV_WGS=<target workgroups per CU * 100>
+        static const char *e_mt = getenv("ZV_CONV_MT");
+        static const char *e_w = getenv("ZV_CONV_WGS");
+        if (e_w)
+        {
+            const long tgt = atol(e_w) * n_cu / 100;
+            MT = 4;
+            while (MT > 1 && wgs(MT) < tgt) MT >>= 1;
+        }
+        if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
+    }
+#define ZV_CASE(mt, wn) \
+    if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, Kh, 1, ck, dmax);
+    ZV_CASE(4, 4) ZV_CASE(2, 4) ZV_CASE(1, 4)
+    ZV_CASE(4, 2) ZV_CASE(2, 2) ZV_CASE(1, 2)
+    ZV_CASE(4, 1) ZV_CASE(2, 1) ZV_CASE(1, 1)
+#undef ZV_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused dilation pair of a HiFi-GAN residual block (reference src/hifigan.cpp:99-182):
+//     xt = lrelu(conv(lrelu(y), k, dil) + b1);  out = y + (conv(xt, k, 1) + b2)
+// One workgroup produces TM = BM - (k-1) output rows: it stages f16(lrelu(y)) for BM + (k-1)*dil rows, runs
+// conv1 over BM rows (the k-1 extra rows are conv2's halo) with the weights as the MFMA A operand so that a
+// lane ends up with 4 consecutive channels per register quad, packs xt = f16(lrelu(. + b1)) straight back
+// into the same LDS region (rows outside [0, L) are conv2's zero padding), runs conv2 from there and adds
+// bias + residual in the epilogue.  xt never touches HBM.
+//
+// The MFMA loop is specialised on the channel count so that every LDS / weight address inside an iteration is
+// an immediate: one body = 8 steps = 8 / (CP/16) taps, the per-body bookkeeping is a handful of vector adds.  The first version of this loop carried ~15 scalar/vector instructions of
+// tap/channel bookkeeping per MFMA and was instruction-issue bound (SQ_ACTIVE_INST_ANY ~ 74 % of the kernel with
+// the MFMA pipe 19 % busy, profiles/r01_v2_pmc.txt).  Weights for this path are packed per 32-channel output
+// tile as round_up(K*CP/16, 4) + 8 blocks, zero blocks behind the real ones: the loop needs no tail handling
+// and its prefetch never leaves the tile's segment.
+size_t pair_weight_halfs(int Cp, int K)
+{
+    const int nkc = Cp / 16;
+    return (size_t)(Cp / 32) * (round_up(K * nkc, 4) + 8) * 512;
+}
+
+void pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
+{
+    const int nkc = Cp / 16;
+    const size_t seg = (size_t)(round_up(K * nkc, 4) + 8) * 512;
+    memset(dst, 0, pair_weight_halfs(Cp, K) * 2);
+    for (int nt = 0; nt < Cp / 32; nt++)
+        for (int tap = 0; tap < K; tap++)
+            for (int kc = 0; kc < nkc; kc++)
+            {
+                uint16_t *d = dst + nt * seg + (size_t)(tap * nkc + kc) * 512;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                    {
+                        const int oc = nt * 32 + (lane & 31), ic = kc * 16 + 8 * (lane >> 5) + j;
+                        d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                    }
+            }
 }
 
 template <int CP, int MT>
