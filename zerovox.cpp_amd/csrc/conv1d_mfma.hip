@@ -516,6 +516,55 @@ void pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
             }
 }
 
+// leaky-ReLU for 0 <= slope <= 1 as max(x, x*slope): same bits as (x > 0 ? x : x*slope), one instruction less and
+// no compare/select pair; raw v_max_f32 keeps hipcc from adding a canonicalising multiply in front of fmaxf
+__device__ __forceinline__ float lrelu_max(float x, float s)
+{
+    float r;
+    const float xs = x * s;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(xs));
+    return r;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Stage f16(lrelu(y)) rows through a buffer descriptor: rows outside [0, L) are out of the descriptor's range and
+// read as 0 (= the conv's zero padding, lrelu(0) = 0) with no per-row predicate; CP is a power of two so the
+// row / column split of the flat index is a shift and a mask.
+template <int U, int CP>
+__device__ __forceinline__ void stage_act_buf(__amdgpu_buffer_rsrc_t rsrc, char *smem, int row_t0, int rows, int tid, float slope)
+{
+    constexpr int RS = CP * 2 + 16, COLS = CP / 4, SH = (CP == 32) ? 3 : (CP == 64 ? 4 : 5);
+    const int total = rows * COLS;
+    for (int base = tid; base < total; base += 256 * U)
+    {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            const int idx = base + u * 256;
+            const int r = idx >> SH, c4 = idx & (COLS - 1);
+            const int voff = (idx < total) ? ((row_t0 + r) * CP + c4 * 4) * 4 : -16;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            const int idx = base + u * 256;
+            if (idx < total)
+            {
+                const int r = idx >> SH, c4 = idx & (COLS - 1);
+                half4 h;
+                h[0] = (_Float16)lrelu_max(__uint_as_float(v[u].x), slope);
+                h[1] = (_Float16)lrelu_max(__uint_as_float(v[u].y), slope);
+                h[2] = (_Float16)lrelu_max(__uint_as_float(v[u].z), slope);
+                h[3] = (_Float16)lrelu_max(__uint_as_float(v[u].w), slope);
+                *(half4 *)(smem + r * RS + c4 * 8) = h;
+            }
+        }
+    }
+}
+
 template <int CP, int MT>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 {
@@ -537,14 +586,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;        // half8 units per n-tile segment
 
     // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
-    {
-        ConvJob cj;
-        cj.x0 = P.y;
-        cj.ldx = CP;
-        cj.L = L;
-        cj.slope = P.slope;
-        if (!(P.dbg & 1)) stage_tile_p<ZV_STAGE_U, PRO_ACT>(cj, smem, RS, 0, CP, t0 - h2 - h1, BM + 2 * h1 + dil, tid);
-    }
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)P.y, 0, L * CP * 4, 0x00020000);
+    if (!(P.dbg & 1)) stage_act_buf<ZV_STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
     __syncthreads();
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
@@ -570,16 +613,19 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         {
             const int i = wm * 32 * MT + mt * 32 + (lane & 31);
             const int t = t0 - h2 + i;
-            const float keep = (t >= 0 && t < L) ? 1.f : 0.f;
+            const bool in = t >= 0 && t < L;
 #pragma unroll
             for (int q = 0; q < 4; q++)
             {
                 half4 h;
-                h[0] = (_Float16)(lrelu(acc[mt][4 * q + 0] + bq[q].x, sl) * keep);
-                h[1] = (_Float16)(lrelu(acc[mt][4 * q + 1] + bq[q].y, sl) * keep);
-                h[2] = (_Float16)(lrelu(acc[mt][4 * q + 2] + bq[q].z, sl) * keep);
-                h[3] = (_Float16)(lrelu(acc[mt][4 * q + 3] + bq[q].w, sl) * keep);
-                *(half4 *)(smem + i * RS + (wn * 32 + 8 * q + 4 * hh) * 2) = h;
+                h[0] = (_Float16)lrelu_max(acc[mt][4 * q + 0] + bq[q].x, sl);
+                h[1] = (_Float16)lrelu_max(acc[mt][4 * q + 1] + bq[q].y, sl);
+                h[2] = (_Float16)lrelu_max(acc[mt][4 * q + 2] + bq[q].z, sl);
+                h[3] = (_Float16)lrelu_max(acc[mt][4 * q + 3] + bq[q].w, sl);
+                uint2 pk = *(uint2 *)&h;
+                pk.x = in ? pk.x : 0u;
+                pk.y = in ? pk.y : 0u;
+                *(uint2 *)(smem + i * RS + (wn * 32 + 8 * q + 4 * hh) * 2) = pk;
             }
         }
     }
@@ -592,29 +638,27 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
     if (!(P.dbg & 2)) mfma_taps<CP, MT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * wseg + lane, K);
 
-    // ---- epilogue: out = y + (conv2 + b2)
+    // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
+    // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
+    // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
     if (P.dbg & 4) return;
     const int oc = wn * 32 + (lane & 31);
     const float bias = P.b2[oc];
-    const int jbase = wm * 32 * MT + 4 * (lane >> 5);
-    const float *yp = P.y + (size_t)t0 * CP + oc;
-    float *op = P.out + (size_t)t0 * CP + oc;
+    const int nrows = (L - t0 < TM) ? (L - t0) : TM;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(P.y + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(P.out + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const int voff = ((wm * 32 * MT + 4 * (lane >> 5)) * CP + oc) * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
     {
         float resv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++)
-        {
-            const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            resv[r] = yp[(j < TM && t0 + j < L) ? j * CP : 0];
-        }
+            resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
 #pragma unroll
         for (int r = 0; r < 16; r++)
-        {
-            const int j = jbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            if (j < TM && t0 + j < L) op[j * CP] = (acc[mt][r] + bias) + resv[r];
-        }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][r] + bias) + resv[r]), rs_out, voff,
+                                                  (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
     }
 }
 
