@@ -196,7 +196,7 @@ __device__ __forceinline__ void stage_tile(const ConvJob &J, char *smem, int RS,
 // (the ds_reads of step s+1 are in flight while the MFMAs of step s run), B fragments come from L2 through a
 // 4-deep register ring.
 template <int MT, bool SWAP = false>
-__device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT], const char *abase, int RS, int dil, const half8 *wp,
+__device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT][1], const char *abase, int RS, int dil, const half8 *wp,
                                            int K, int nkc)
 {
     // Branch-free, 4 steps per iteration with static register slots so that hipcc can count its waits: the B
@@ -228,9 +228,9 @@ __device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT], const char *abas
             {
                 // SWAP: weights as the A operand -> D[oc][time] (4 consecutive channels per lane register quad)
                 if constexpr (SWAP)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bu, a[mt], acc[mt], 0, 0, 0);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bu, a[mt], acc[mt][0], 0, 0, 0);
                 else
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bu, acc[mt], 0, 0, 0);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bu, acc[mt][0], 0, 0, 0);
             }
             const int sn = s0 + u + 4;
             b[u] = wp[(size_t)((sn < S) ? sn : S - 1) * 64];
@@ -240,38 +240,44 @@ __device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT], const char *abas
     }
 }
 
-template <int MT, bool SWAP>
-__device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT], const half8 (&a)[MT], const half8 &b)
+template <int MT, int NT, bool SWAP>
+__device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT][NT], const half8 (&a)[MT], const half8 (&b)[NT])
 {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
-    {
-        if constexpr (SWAP)      // weights as the A operand -> D[oc][time]
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a[mt], acc[mt], 0, 0, 0);
-        else
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b, acc[mt], 0, 0, 0);
-    }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+        {
+            if constexpr (SWAP)      // weights as the A operand -> D[oc][time]
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+            else
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
 }
 
-// One body = 8 MFMA steps = 8 / (CP/16) taps.  Two static B register sets ping-pong (b0: steps 0-3, b1: steps 4-7),
-// each refilled for the next body right after its last use; A fragments ping-pong one step ahead.  All LDS and
-// weight addresses inside a body are immediates off (ap + tap * dilRS) and wq.
-template <int CP, int MT, bool SWAP>
-__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT], const char *ap, int dilRS, const half8 *wq, int K)
+// One body = 8 MFMA steps = 8 / (CP/16) taps (half a tap for CP = 256).  Two static B register sets ping-pong
+// (b0: steps 0-3, b1: steps 4-7), each refilled for the next body right after its last use; A fragments ping-pong
+// one step ahead.  All LDS and weight addresses inside a body are immediates off the body's base.  A wave covers
+// NT output tiles of 32 channels (their weight segments are `wseg` half8 apart) and MT row tiles.
+template <int CP, int MT, int NT, bool SWAP>
+__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
 {
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    constexpr int TPB = 8 / NKC;                 // taps per body: 4 / 2 / 1 for CP = 32 / 64 / 128
-    const int nsb = (K * NKC + 3) >> 2;          // 4-step sub-blocks (the last one may run partly on zero weights)
+    constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;        // taps per body: 4 / 2 / 1 / (1/2) for CP = 32 / 64 / 128 / 256
+    constexpr bool HALF = NKC == 16;                     // CP = 256: a tap is two bodies (channels 0-127, 128-255)
+    const int nsb = (K * NKC + 3) >> 2;                  // 4-step sub-blocks (the last one may run partly on zero weights)
     const int nb = nsb >> 1;
-    half8 b0[4], b1[4];
+    half8 b0[4][NT], b1[4][NT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) b0[u] = wq[u * 64];
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + u * 64];
     wq += 4 * 64;
     half8 a0[MT], a1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) a0[mt] = *(const half8 *)(ap + mt * 32 * RS);
 
-#define ZV_A_ADDR(un) ((un) == 8 ? ap + TPB * dilRS : tb[((un) / NKC) % TPB] + ((un) % NKC) * 32)
+#define ZV_A_ADDR(un) ((un) == 8 ? apn : tb[((un) / NKC) % 4] + ((un) % NKC) * 32)
 #define ZV_LOAD_A(dst, un)                                                                   \
     {                                                                                        \
         const char *np_ = ZV_A_ADDR(un);                                                     \
@@ -283,30 +289,37 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT], const char *ap, i
         tb[0] = ap;
 #pragma unroll
         for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
+        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + TPB * dilRS;   // next body
 #pragma unroll
-        for (int u = 0; u < 4; u++) b1[u] = wq[u * 64];                  // steps 4..7 of this body
-        __builtin_amdgcn_sched_barrier(0);      // keep the four requests here: hipcc otherwise sinks them next to their use
-        ZV_LOAD_A(a1, 1) mfma_step<MT, SWAP>(acc, a0, b0[0]);
-        ZV_LOAD_A(a0, 2) mfma_step<MT, SWAP>(acc, a1, b0[1]);
-        ZV_LOAD_A(a1, 3) mfma_step<MT, SWAP>(acc, a0, b0[2]);
-        ZV_LOAD_A(a0, 4) mfma_step<MT, SWAP>(acc, a1, b0[3]);
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) b0[u] = wq[(4 + u) * 64];            // steps 0..3 of the next body
+            for (int nt = 0; nt < NT; nt++) b1[u][nt] = wq[nt * wseg + u * 64];      // steps 4..7 of this body
+        __builtin_amdgcn_sched_barrier(0);      // keep the requests here: hipcc otherwise sinks them next to their use
+        ZV_LOAD_A(a1, 1) mfma_step<MT, NT, SWAP>(acc, a0, b0[0]);
+        ZV_LOAD_A(a0, 2) mfma_step<MT, NT, SWAP>(acc, a1, b0[1]);
+        ZV_LOAD_A(a1, 3) mfma_step<MT, NT, SWAP>(acc, a0, b0[2]);
+        ZV_LOAD_A(a0, 4) mfma_step<MT, NT, SWAP>(acc, a1, b0[3]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + (4 + u) * 64];   // steps 0..3 of the next body
         __builtin_amdgcn_sched_barrier(0);
-        ZV_LOAD_A(a1, 5) mfma_step<MT, SWAP>(acc, a0, b1[0]);
-        ZV_LOAD_A(a0, 6) mfma_step<MT, SWAP>(acc, a1, b1[1]);
-        ZV_LOAD_A(a1, 7) mfma_step<MT, SWAP>(acc, a0, b1[2]);
-        ZV_LOAD_A(a0, 8) mfma_step<MT, SWAP>(acc, a1, b1[3]);
-        ap += TPB * dilRS;
+        ZV_LOAD_A(a1, 5) mfma_step<MT, NT, SWAP>(acc, a0, b1[0]);
+        ZV_LOAD_A(a0, 6) mfma_step<MT, NT, SWAP>(acc, a1, b1[1]);
+        ZV_LOAD_A(a1, 7) mfma_step<MT, NT, SWAP>(acc, a0, b1[2]);
+        ZV_LOAD_A(a0, 8) mfma_step<MT, NT, SWAP>(acc, a1, b1[3]);
+        ap = apn;
         wq += 8 * 64;
     }
     if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
     {
         const char *tb[4] = {ap, ap, ap, ap};
-        ZV_LOAD_A(a1, 1) mfma_step<MT, SWAP>(acc, a0, b0[0]);
-        ZV_LOAD_A(a0, 2) mfma_step<MT, SWAP>(acc, a1, b0[1]);
-        ZV_LOAD_A(a1, 3) mfma_step<MT, SWAP>(acc, a0, b0[2]);
-        mfma_step<MT, SWAP>(acc, a1, b0[3]);
+        const char *apn = ap;
+        (void)apn;
+        ZV_LOAD_A(a1, 1) mfma_step<MT, NT, SWAP>(acc, a0, b0[0]);
+        ZV_LOAD_A(a0, 2) mfma_step<MT, NT, SWAP>(acc, a1, b0[1]);
+        ZV_LOAD_A(a1, 3) mfma_step<MT, NT, SWAP>(acc, a0, b0[2]);
+        mfma_step<MT, NT, SWAP>(acc, a1, b0[3]);
     }
 #undef ZV_LOAD_A
 #undef ZV_A_ADDR
@@ -338,11 +351,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     const int rows = BM + (K - 1) * dil;
     const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
 
-    floatx16 acc[MT];
+    floatx16 acc[MT][1];
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[i][0][r] = 0.f;
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
 
@@ -358,9 +371,9 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
             // full chunks of 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there and
             // the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
             if (ck == 128 && J.ck == 128)
-                mfma_taps<128, MT, false>(acc, abase, dil * RS, wp, K);
+                mfma_taps<128, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
             else if (ck == 64 && J.ck == 64)
-                mfma_taps<64, MT, false>(acc, abase, dil * RS, wp, K);
+                mfma_taps<64, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
             else
                 mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
         }
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
             const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
             if (t < L)
             {
-                float v = acc[mt][r] + bias;
+                float v = acc[mt][0][r] + bias;
                 if (has_res) v = v + resv[r];
                 v = v * escale;
                 if (J.eact) v = lrelu(v, J.oslope);
@@ -534,7 +547,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int U, int CP>
 __device__ __forceinline__ void stage_act_buf(__amdgpu_buffer_rsrc_t rsrc, char *smem, int row_t0, int rows, int tid, float slope)
 {
-    constexpr int RS = CP * 2 + 16, COLS = CP / 4, SH = (CP == 32) ? 3 : (CP == 64 ? 4 : 5);
+    constexpr int RS = CP * 2 + 16, COLS = CP / 4, SH = (CP == 32) ? 3 : (CP == 64 ? 4 : (CP == 128 ? 5 : 6));
     const int total = rows * COLS;
     for (int base = tid; base < total; base += 256 * U)
     {
@@ -568,7 +581,8 @@ __device__ __forceinline__ void stage_act_buf(__amdgpu_buffer_rsrc_t rsrc, char 
 template <int CP, int MT>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 {
-    constexpr int WN = CP / 32, WM = 4 / WN;
+    constexpr int NT = (CP == 256) ? 2 : 1;            // output tiles of 32 channels per wave
+    constexpr int WN = CP / 32 / NT, WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     const PairJob &P = jobs.j[blockIdx.z];
@@ -591,41 +605,48 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     __syncthreads();
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-    floatx16 acc[MT];
+    floatx16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
-    if (!(P.dbg & 2)) mfma_taps<CP, MT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * wseg + lane, K);
+    if (!(P.dbg & 2)) mfma_taps<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K);
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
 
     // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
     {
         const int hh = lane >> 5;
-        float4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + wn * 32 + 8 * q + 4 * hh);
         const float sl = P.slope;
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int nt = 0; nt < NT; nt++)
         {
-            const int i = wm * 32 * MT + mt * 32 + (lane & 31);
-            const int t = t0 - h2 + i;
-            const bool in = t >= 0 && t < L;
+            const int ocb = (wn * NT + nt) * 32;
+            float4 bq[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + ocb + 8 * q + 4 * hh);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
             {
-                half4 h;
-                h[0] = (_Float16)lrelu_max(acc[mt][4 * q + 0] + bq[q].x, sl);
-                h[1] = (_Float16)lrelu_max(acc[mt][4 * q + 1] + bq[q].y, sl);
-                h[2] = (_Float16)lrelu_max(acc[mt][4 * q + 2] + bq[q].z, sl);
-                h[3] = (_Float16)lrelu_max(acc[mt][4 * q + 3] + bq[q].w, sl);
-                uint2 pk = *(uint2 *)&h;
-                pk.x = in ? pk.x : 0u;
-                pk.y = in ? pk.y : 0u;
-                *(uint2 *)(smem + i * RS + (wn * 32 + 8 * q + 4 * hh) * 2) = pk;
+                const int i = wm * 32 * MT + mt * 32 + (lane & 31);
+                const int t = t0 - h2 + i;
+                const bool in = t >= 0 && t < L;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    half4 h;
+                    h[0] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 0] + bq[q].x, sl);
+                    h[1] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 1] + bq[q].y, sl);
+                    h[2] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 2] + bq[q].z, sl);
+                    h[3] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 3] + bq[q].w, sl);
+                    uint2 pk = *(uint2 *)&h;
+                    pk.x = in ? pk.x : 0u;
+                    pk.y = in ? pk.y : 0u;
+                    *(uint2 *)(smem + i * RS + (ocb + 8 * q + 4 * hh) * 2) = pk;
+                }
             }
         }
     }
@@ -635,39 +656,46 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-    if (!(P.dbg & 2)) mfma_taps<CP, MT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * wseg + lane, K);
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
+    if (!(P.dbg & 2)) mfma_taps<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
     // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
     // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
     if (P.dbg & 4) return;
-    const int oc = wn * 32 + (lane & 31);
-    const float bias = P.b2[oc];
     const int nrows = (L - t0 < TM) ? (L - t0) : TM;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(P.y + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(P.out + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-    const int voff = ((wm * 32 * MT + 4 * (lane >> 5)) * CP + oc) * 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int nt = 0; nt < NT; nt++)
     {
-        float resv[16];
+        const int oc = (wn * NT + nt) * 32 + (lane & 31);
+        const float bias = P.b2[oc];
+        const int voff = ((wm * 32 * MT + 4 * (lane >> 5)) * CP + oc) * 4;
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+        for (int mt = 0; mt < MT; mt++)
+        {
+            float resv[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][r] + bias) + resv[r]), rs_out, voff,
-                                                  (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+            for (int r = 0; r < 16; r++)
+                resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[r]), rs_out, voff,
+                                                      (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+        }
     }
 }
 
-bool pair_supported(int Cp) { return Cp == 32 || Cp == 64 || Cp == 128; }
+bool pair_supported(int Cp) { return Cp == 32 || Cp == 64 || Cp == 128 || Cp == 256; }
 
 template <int CP, int MT>
 static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
 {
-    constexpr int BM = 32 * MT * (4 / (CP / 32));
+    constexpr int WNc = (CP == 256) ? 4 : CP / 32;
+    constexpr int BM = 32 * MT * (4 / WNc);
     const int TMmin = BM - (Kmax - 1);
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
@@ -702,7 +730,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
     }
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
     const int Cp = jobs[0].Cp;
-    const int WN = Cp / 32;
+    const int WN = Cp == 256 ? 4 : Cp / 32;
     auto wgs = [&](int MT) {
         const int BM = 32 * MT * (4 / WN);
         const int TM = BM - (Kmax - 1);
@@ -717,7 +745,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
     if (mt_env == 2 || mt_env == 4) MT = mt_env;
 #define ZV_PCASE(cp, mt) \
     if (Cp == cp && MT == mt) return launch_pair_cfg<cp, mt>(s, js, njobs, Lmax, Kmax, dmax);
-    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2)
+    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2)
 #undef ZV_PCASE
     return hipErrorInvalidValue;
 }

@@ -645,7 +645,11 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         // (conv -> lrelu -> conv -> + residual, xt kept in LDS), y ping-pongs between two buffers because a
         // workgroup's halo rows belong to its neighbours' output tiles.
         const ResPair &rp0 = voc_.pairs[((size_t)i * voc_.n_rb) * voc_.n_dil];
-        const bool fused = !no_fuse_ && rp0.p1 != nullptr;
+        // 256-channel stage: the fused kernel needs all 256 xt channels in one workgroup, which leaves only
+        // ceil(L/54) workgroups per branch — measured slower than two unfused launches (480 workgroups) until the
+        // stage has enough rows to give every CU two of them (long / batched utterances)
+        const bool enough_rows = Cp != 256 || (long)(L / 54) * 3 >= 2L * n_cu;
+        const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
         for (int d = 0; d < voc_.n_dil; d++)
         {
