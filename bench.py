@@ -167,6 +167,29 @@ def main():
             model.vocode(mel)
         extra["pcie_inclusive_xrt"] = round(reps * audio_s / (time.perf_counter() - t1), 1)
         extra["kernels"] = kernels
+        # the other single-GPU configs of BASELINE.json, reported for reference (never `value`):
+        #   configs[2] full chain phoneme -> wav, 128 phonemes, T = 512, batch 1 (host buffers in/out)
+        #   configs[3] batch of 32 mixed-length utterances (32..256 phonemes), T = 1024 each, 4 in-flight lanes
+        try:
+            from zerovox_cpp_amd import sharding
+            model.set_graph_mode(False)
+            ids, puncts, style = synth.encoder_inputs(g, 5, 128)
+            for _ in range(3):
+                model.synthesize(ids, puncts, style, T)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model.synthesize(ids, puncts, style, T)
+            extra["full_chain_128ph_T%d_xrt" % T] = round(10 * audio_s / (time.perf_counter() - t1), 1)
+            utts = []
+            for u, n in enumerate(sharding.mixed_length_batch(3, 32)):
+                i_, p_, s_ = synth.encoder_inputs(g, 200 + u, n)
+                utts.append((i_, p_, s_, 1024))
+            model.synthesize_batch(utts[:4])
+            t1 = time.perf_counter()
+            model.synthesize_batch(utts)
+            extra["batch32_mixed_T1024_xrt"] = round(32 * 1024 * hop / sr / (time.perf_counter() - t1), 1)
+        except Exception as e:      # these extras must never take the headline measurement down
+            extra["extras_error"] = str(e)
 
     # ---- CPU baseline on this host's cores (rank 0, N = 1 only) ----
     cpu = None

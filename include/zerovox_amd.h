@@ -101,6 +101,14 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav);
 zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
                         uint32_t n, uint32_t T, float *wav, uint32_t *n_frames);
 
+/* n_utt independent utterances, each with its own (n_phonemes[u], T[u]) exactly as if zv_synthesize had been
+ * called per utterance (no batch padding: padding would change the numbers, SURVEY Appx C-H2); utterances are
+ * spread over up to 4 in-flight lanes (stream + arena each) so that the narrow stages of short utterances overlap.
+ * BASELINE.json configs[3]/[4]; with several GPUs the caller shards the list (one model per GPU). */
+zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
+                              const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T,
+                              float *const *wav, uint32_t *n_frames);
+
 /* ---- device-resident variants (inputs already in HBM; enqueue on the model's stream) ------- */
 void     *zv_device_alloc(zv_model *m, size_t bytes);
 void      zv_device_free(zv_model *m, void *p);

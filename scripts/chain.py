@@ -28,3 +28,23 @@ tot = sum(s["total_ms"] for s in st)
 for s in st:
     print(f"  {s['name']:22s} launches/utt {s['launches']//5:3d}  ms/utt {s['total_ms']/5:.4f}  share {s['total_ms']/tot:.3f}  TF {s['algo_flops']/(s['total_ms']*1e-3)/1e12 if s['total_ms'] else 0:.1f}")
 print("  total kernel ms/utt (event-timed)", tot / 5)
+
+# ---- BASELINE.json configs[3]: batch = 32 mixed-length utterances (32..256 phonemes), T = 1024 each
+from zerovox_cpp_amd import sharding
+lens = sharding.mixed_length_batch(3, 32)
+utts = []
+for u, n in enumerate(lens):
+    i, p, s = synth.encoder_inputs(g, 200 + u, n)
+    utts.append((i, p, s, 1024))
+m.reserve(256, 1024)
+m.synthesize_batch(utts[:8])
+t0 = time.perf_counter()
+out = m.synthesize_batch(utts)
+dt = time.perf_counter() - t0
+audio = sum(1024 * 300 / 22050 for _ in utts)
+print(f"batch 32 x T=1024 (4 lanes): {dt*1e3:.1f} ms -> {audio/dt:.0f} xRT whole-batch audio-seconds/second (all T frames vocoded, like the reference)")
+t0 = time.perf_counter()
+for (i, p, s, T) in utts:
+    m.synthesize(i, p, s, T)
+dt1 = time.perf_counter() - t0
+print(f"same 32 utterances one by one: {dt1*1e3:.1f} ms -> {audio/dt1:.0f} xRT")

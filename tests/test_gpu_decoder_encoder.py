@@ -124,3 +124,21 @@ def test_synthesize_end_to_end(models):
     wav2 = model.vocode(mel)
     assert nf == e["n_frames"] and wav.shape == (T * g.hop_size,)
     assert np.array_equal(wav, wav2)          # same kernels, same order: the fused path is deterministic
+
+
+def test_synthesize_batch_equals_per_utterance(models):
+    """configs[3]/[4]: mixed-length utterances run on several in-flight lanes; every utterance keeps its own (N, T)
+    and must come out bit-identical to a stand-alone zv_synthesize call (no batch padding, deterministic kernels)"""
+    from zerovox_cpp_amd import sharding, synth
+    model, g, tensors = models("small")
+    lens = [min(n, 96) for n in sharding.mixed_length_batch(11, 7)]
+    utts = []
+    for u, n in enumerate(lens):
+        ids, puncts, style = synth.encoder_inputs(g, 100 + u, n)
+        utts.append((ids, puncts, style, 64 + 32 * (u % 3)))
+    got = model.synthesize_batch(utts)
+    for (ids, puncts, style, T), (wav, nf) in zip(utts, got):
+        ref, nf_ref = model.synthesize(ids, puncts, style, T)
+        assert nf == nf_ref and wav.shape == ref.shape
+        assert np.array_equal(wav, ref)
+    assert model.synthesize_batch([]) == []

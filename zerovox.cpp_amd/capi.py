@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ZEROVOX_AMD_LIB") or os.path.join(HERE, "libzerovox_a
 # every symbol include/zerovox_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
-    "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_device_alloc", "zv_device_free",
+    "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
     "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect",
 ]
@@ -68,6 +68,8 @@ def load_library(path: Optional[str] = None):
     lib.zv_decode.argtypes = [vp, fp, fp, u32, fp]
     lib.zv_vocode.argtypes = [vp, fp, u32, fp]
     lib.zv_synthesize.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
+    lib.zv_synthesize_batch.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32),
+                                        C.POINTER(vp), C.POINTER(u32)]
     lib.zv_device_alloc.argtypes = [vp, C.c_size_t]
     lib.zv_device_alloc.restype = vp
     lib.zv_device_free.argtypes = [vp, vp]
@@ -161,6 +163,25 @@ class Model:
         nf = C.c_uint32(0)
         self._chk(self.lib.zv_synthesize(self.h, _ptr(ids), _ptr(puncts), _ptr(style), len(ids), T, _ptr(wav), C.byref(nf)))
         return wav, int(nf.value)
+
+    def synthesize_batch(self, utterances):
+        """utterances: list of (ids, puncts, style, T) -> list of (wav, n_frames); each utterance keeps its own (N, T)"""
+        n = len(utterances)
+        keep, wavs = [], []
+        P = C.c_void_p * n
+        ids_p, pun_p, sty_p, wav_p = P(), P(), P(), P()
+        Ns, Ts, nf = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_uint32 * n)()
+        for i, (ids, puncts, style, T) in enumerate(utterances):
+            a = np.ascontiguousarray(ids, dtype=np.int32)
+            b = np.ascontiguousarray(puncts, dtype=np.int32)
+            c = np.ascontiguousarray(style, dtype=np.float32)
+            w = np.empty(T * self.hp.audio_hop_size, np.float32)
+            keep += [a, b, c]
+            wavs.append(w)
+            ids_p[i], pun_p[i], sty_p[i], wav_p[i] = a.ctypes.data, b.ctypes.data, c.ctypes.data, w.ctypes.data
+            Ns[i], Ts[i] = len(a), T
+        self._chk(self.lib.zv_synthesize_batch(self.h, n, ids_p, pun_p, sty_p, Ns, Ts, wav_p, nf))
+        return [(wavs[i], int(nf[i])) for i in range(n)]
 
     # ---- device-resident API ----
     def device_alloc(self, nbytes: int) -> int:

@@ -170,6 +170,30 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
     });
 }
 
+// one utterance end to end on the currently selected lane; no host synchronisation
+static void synthesize_enqueue(Model &M, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
+                               float *wav, int32_t *nf_host)
+{
+    check_ids(M, ids, puncts, n);
+    const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_ids = al((size_t)n * 4), b_sty = al(E * 4), b_hid = al((size_t)T * E * 4), b_mel = al((size_t)T * Mm * 4),
+                 b_wav = al((size_t)T * hop * 4);
+    M.reserve(n, T);
+    char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + b_mel + b_wav);
+    int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
+    float *d_sty = (float *)(io + 2 * b_ids), *d_hid = (float *)(io + 2 * b_ids + b_sty);
+    float *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
+    ZV_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+    ZV_HIP(hipMemcpyAsync(d_pun, puncts, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+    ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
+    Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
+    ZV_HIP(hipMemcpyAsync(nf_host, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
+    M.decode_dev(d_hid, d_sty, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
+    M.vocode_dev(d_mel, T, d_wav);
+    ZV_HIP(hipMemcpyAsync(wav, d_wav, (size_t)T * hop * 4, hipMemcpyDeviceToHost, M.stream));
+}
+
 zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
                         float *wav, uint32_t *n_frames)
 {
@@ -178,27 +202,56 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
         ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
         Model &M = *m->m;
         ZV_HIP(hipSetDevice(M.device));
-        check_ids(M, ids, puncts, n);
-        const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
-        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t b_ids = al((size_t)n * 4), b_sty = al(E * 4), b_hid = al((size_t)T * E * 4), b_mel = al((size_t)T * Mm * 4),
-                     b_wav = al((size_t)T * hop * 4);
-        M.reserve(n, T);
-        char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + b_mel + b_wav);
-        int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
-        float *d_sty = (float *)(io + 2 * b_ids), *d_hid = (float *)(io + 2 * b_ids + b_sty);
-        float *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
-        ZV_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
-        ZV_HIP(hipMemcpyAsync(d_pun, puncts, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
-        ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
-        Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
+        M.select_lane(0);
         int32_t nf = 0;
-        ZV_HIP(hipMemcpyAsync(&nf, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
-        M.decode_dev(d_hid, d_sty, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
-        M.vocode_dev(d_mel, T, d_wav);
-        ZV_HIP(hipMemcpyAsync(wav, d_wav, (size_t)T * hop * 4, hipMemcpyDeviceToHost, M.stream));
+        synthesize_enqueue(M, ids, puncts, style, n, T, wav, &nf);
         M.sync();
         if (n_frames) *n_frames = (uint32_t)nf;
+    });
+}
+
+zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
+                              const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T, float *const *wav,
+                              uint32_t *n_frames)
+{
+    return guarded([&] {
+        ZV_NEED(m && ids && puncts && styles && n_phonemes && T && wav, "null argument");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        for (uint32_t u = 0; u < n_utt; u++)
+        {
+            ZV_NEED(ids[u] && puncts[u] && styles[u] && wav[u], "null utterance pointer");
+            ZV_NEED(n_phonemes[u] > 0 && T[u] > 0, "n and T must be > 0");
+        }
+        // outputs land in pinned staging first: a D2H copy into the caller's pageable buffers would block the host
+        // until the utterance has finished and the lanes would run one after the other
+        const size_t hop = M.hp.audio_hop_size;
+        std::vector<size_t> off(n_utt + 1, 0);
+        for (uint32_t u = 0; u < n_utt; u++) off[u + 1] = off[u] + (((size_t)T[u] * hop * 4 + 255) & ~(size_t)255);
+        char *pin = (char *)M.pinned_scratch(off[n_utt] + (size_t)n_utt * 4 + 256);
+        int32_t *nf = (int32_t *)(pin + off[n_utt]);
+        const int lanes = n_utt < 4 ? (int)(n_utt ? n_utt : 1) : 4;
+        try
+        {
+            for (uint32_t u = 0; u < n_utt; u++)
+            {
+                M.select_lane((int)(u % lanes));
+                synthesize_enqueue(M, ids[u], puncts[u], styles[u], n_phonemes[u], T[u], (float *)(pin + off[u]), &nf[u]);
+            }
+        }
+        catch (...)
+        {
+            try { M.sync_all_lanes(); } catch (...) {}
+            M.select_lane(0);
+            throw;
+        }
+        M.sync_all_lanes();
+        M.select_lane(0);
+        for (uint32_t u = 0; u < n_utt; u++)
+        {
+            memcpy(wav[u], pin + off[u], (size_t)T[u] * hop * 4);
+            if (n_frames) n_frames[u] = (uint32_t)nf[u];
+        }
     });
 }
 

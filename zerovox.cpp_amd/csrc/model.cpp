@@ -144,6 +144,8 @@ Model::Model(const std::string &path, int dev) : device(dev)
     n_cu = prop.multiProcessorCount;
     no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    lanes_.resize(1);
+    lanes_[0].stream = stream;
 
     GgufFile g;
     g.open(path);
@@ -422,16 +424,70 @@ Model::Model(const std::string &path, int dev) : device(dev)
 Model::~Model()
 {
     hipSetDevice(device);
-    if (stream) hipStreamSynchronize(stream);
+    stash_lane();
+    for (Lane &l : lanes_)
+        if (l.stream) hipStreamSynchronize(l.stream);
     drop_graphs();
     prof_clear();
     for (void *p : allocs_) hipFree(p);
-    if (arena_.base) hipFree(arena_.base);
-    if (io_) hipFree(io_);
-    if (stream) hipStreamDestroy(stream);
+    if (pinned_) hipHostFree(pinned_);
+    for (Lane &l : lanes_)
+    {
+        if (l.arena.base) hipFree(l.arena.base);
+        if (l.io) hipFree(l.io);
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
 }
 
 void Model::sync() { ZV_HIP(hipStreamSynchronize(stream)); }
+
+void Model::stash_lane()
+{
+    if (lanes_.empty()) return;
+    Lane &l = lanes_[cur_lane_];
+    l.stream = stream;
+    l.arena = arena_;
+    l.io = io_;
+    l.io_cap = io_cap_;
+}
+
+void Model::select_lane(int i)
+{
+    if (i < 0 || i >= 16) fail(ZV_ERR_ARG, "lane %d out of range", i);
+    if (i == cur_lane_ && (size_t)i < lanes_.size()) return;
+    stash_lane();
+    while ((int)lanes_.size() <= i)
+    {
+        Lane l;
+        ZV_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        lanes_.push_back(l);
+    }
+    cur_lane_ = i;
+    stream = lanes_[i].stream;
+    arena_ = lanes_[i].arena;
+    io_ = lanes_[i].io;
+    io_cap_ = lanes_[i].io_cap;
+}
+
+void Model::sync_all_lanes()
+{
+    stash_lane();
+    for (Lane &l : lanes_) ZV_HIP(hipStreamSynchronize(l.stream));
+}
+
+void *Model::pinned_scratch(size_t bytes)
+{
+    if (bytes > pinned_cap_)
+    {
+        sync_all_lanes();
+        if (pinned_) hipHostFree(pinned_);
+        pinned_ = nullptr;
+        pinned_cap_ = 0;
+        if (hipHostMalloc(&pinned_, bytes, hipHostMallocDefault) != hipSuccess) fail(ZV_ERR_OOM, "hipHostMalloc(%zu) failed", bytes);
+        pinned_cap_ = bytes;
+    }
+    return pinned_;
+}
 
 void *Model::io_scratch(size_t bytes)
 {
@@ -480,7 +536,7 @@ void Model::arena_require(size_t bytes)
 {
     if (bytes <= arena_.cap) return;
     ZV_HIP(hipStreamSynchronize(stream));
-    drop_graphs();
+    if (cur_lane_ == 0) drop_graphs();
     if (arena_.base) hipFree(arena_.base);
     arena_ = DeviceArena();
     void *p = nullptr;
@@ -741,7 +797,7 @@ void Model::drop_graphs()
 
 void Model::vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav)
 {
-    if (!graph_mode || profiling)
+    if (!graph_mode || profiling || cur_lane_ != 0)
     {
         vocode_dev(d_mel, T, d_wav);
         return;

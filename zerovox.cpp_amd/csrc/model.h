@@ -80,8 +80,18 @@ class Model
     void reserve(uint32_t max_phonemes, uint32_t max_frames);
     void sync();
 
+    // Lanes: independent (stream, activation arena, I/O scratch) triples so that several utterances are in flight at
+    // once (zv_synthesize_batch): a single short utterance cannot fill 256 CUs in its narrow stages, four can.
+    // `stream` / the arena below always refer to the selected lane; lane 0 is the default.
+    void select_lane(int i);
+    int  current_lane() const { return cur_lane_; }
+    void sync_all_lanes();
+
     // scratch for host-buffer entry points (grows on demand)
     void *io_scratch(size_t bytes);
+    // pinned host staging for batched D2H copies (an async copy into pageable memory blocks the host and would
+    // serialise the lanes)
+    void *pinned_scratch(size_t bytes);
 
     // graph replay of the vocoder schedule
     bool graph_mode = false;
@@ -169,6 +179,19 @@ class Model
     ConvJob job(const ConvW &w, int L) const;
     void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
     void tock(hipEvent_t e0, const char *name, double bytes, double flops);
+
+    struct Lane
+    {
+        hipStream_t stream = nullptr;
+        DeviceArena arena;
+        void       *io = nullptr;
+        size_t      io_cap = 0;
+    };
+    std::vector<Lane> lanes_;
+    void  *pinned_ = nullptr;
+    size_t pinned_cap_ = 0;
+    int  cur_lane_ = 0;
+    void stash_lane();
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     std::vector<VocoderGraph> graphs_;
