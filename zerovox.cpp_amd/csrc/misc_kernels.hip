@@ -27,34 +27,34 @@ __device__ __forceinline__ float wave_max_f(float v)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// InstanceNorm1d statistics over time for 32 channels per block (ggml_norm: mean and biased variance of
-// (x - mean) accumulated in f64, scale = 1/sqrtf(var + eps); reference ggml-cpu.c:6906-6923).
-// 512 threads = 32 channels (coalesced 128-B rows) x 16 time lanes.
-__global__ __launch_bounds__(512) void in_stats_kernel(const float *__restrict__ x, int ld, int L, int C, float eps,
-                                                       float *__restrict__ stat)
+// InstanceNorm1d statistics over time (ggml_norm: mean and biased variance of (x - mean) accumulated in f64,
+// scale = 1/sqrtf(var + eps); reference ggml-cpu.c:6906-6923).  1024 threads = 16 channels (64-B row segments)
+// x 64 time lanes: the kernel is pure latency (a few MB), so it is cut into many short strided loops.
+__global__ __launch_bounds__(1024) void in_stats_kernel(const float *__restrict__ x, int ld, int L, int C, float eps,
+                                                        float *__restrict__ stat)
 {
-    __shared__ double red[16][33];
-    __shared__ float meanv[32];
-    const int cl = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[64][17];
+    __shared__ float meanv[16];
+    const int cl = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const bool ok = c < C;
     double s = 0.0;
     if (ok)
-        for (int t = ty; t < L; t += 16) s += (double)x[(size_t)t * ld + c];
+        for (int t = ty; t < L; t += 64) s += (double)x[(size_t)t * ld + c];
     red[ty][cl] = s;
     __syncthreads();
     if (ty == 0)
     {
         double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) tot += red[i][cl];
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) tot += red[i][cl];
         meanv[cl] = (float)(tot / (double)L);
     }
     __syncthreads();
     const float mean = meanv[cl];
     double s2 = 0.0;
     if (ok)
-        for (int t = ty; t < L; t += 16)
+        for (int t = ty; t < L; t += 64)
         {
             const float v = x[(size_t)t * ld + c] - mean;
             s2 += (double)(v * v);
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(512) void in_stats_kernel(const float *__restrict__
     if (ty == 0 && ok)
     {
         double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) tot += red[i][cl];
+#pragma unroll 8
+        for (int i = 0; i < 64; i++) tot += red[i][cl];
         const float var = (float)(tot / (double)L);
         stat[2 * c] = mean;
         stat[2 * c + 1] = 1.0f / sqrtf(var + eps);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void in_stats_kernel(const float *__restrict__
 
 hipError_t launch_in_stats(hipStream_t s, const float *x, int ld, int L, int C, float eps, float *stat)
 {
-    hipLaunchKernelGGL(in_stats_kernel, dim3((C + 31) / 32), dim3(512), 0, s, x, ld, L, C, eps, stat);
+    hipLaunchKernelGGL(in_stats_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, x, ld, L, C, eps, stat);
     return hipGetLastError();
 }
 
@@ -100,66 +100,78 @@ hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int L, int 
 
 // ---------------------------------------------------------------------------------------------------
 // y[n][o] = dot(W[o][:], x[n][:]) + b[o]   (f32 weights: ggml_mul_mat + ggml_add, reference
-// src/fs2encoder.cpp:77-89,127-128 and src/stylettsdec.cpp:178-179).  32 outputs x 16 rows per block,
-// k tiled by 32 through LDS, fused multiply-add accumulation like ggml's AVX2+FMA vec_dot.
+// src/fs2encoder.cpp:77-89,127-128 and src/stylettsdec.cpp:178-179) on the f32-input matrix cores:
+// v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (exact f32, the reference's own FMA accumulation),
+// one wave per 32 rows x 32 outputs.  Lane l holds A[row l&31][k + (l>>5)] / B[k + (l>>5)][col l&31].
 // `extra[o]` is added after the bias (AdaIN: gamma = h[:C] + 1, src/stylettsdec.cpp:186-189).
-__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int ldx, int n, int in,
-                                                     const float *__restrict__ W, const float *__restrict__ b, int out,
-                                                     float *__restrict__ y, int ldy, const float *__restrict__ extra)
+typedef float floatx16m __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void linear_mfma_kernel(const float *__restrict__ x, int ldx, int n, int in,
+                                                         const float *__restrict__ W, const float *__restrict__ b, int out,
+                                                         float *__restrict__ y, int ldy, const float *__restrict__ extra)
 {
-    __shared__ float Wt[32][33];
-    __shared__ float Xt[16][33];
-    const int tid = threadIdx.x;
-    const int o0 = blockIdx.x * 32, n0 = blockIdx.y * 16;
-    const int ol = tid & 31, nl = tid >> 5;          // nl in 0..7 -> rows nl and nl+8
-    float acc0 = 0.f, acc1 = 0.f;
+    // 32 x 32 k-chunks of both operands go through LDS: global rows are read as coalesced 128-B segments, the MFMA
+    // operand (one f32 per lane, rows across lanes) comes back from LDS with a 33-float row stride (conflict-free)
+    __shared__ float Xs[32][33];
+    __shared__ float Ws[32][33];
+    const int lane = threadIdx.x;
+    const int o0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int i = lane & 31, kk = lane >> 5;
+    floatx16m acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float4 xv[4], wv[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int idx = lane + u * 64, r = idx >> 3, c = (idx & 7) * 4;
+            const bool kin = k0 + c < in;                      // `in` is a multiple of 4: a float4 is all in or all out
+            const int row = n0 + r, col = o0 + r;
+            xv[u] = (kin && row < n) ? *(const float4 *)(x + (size_t)row * ldx + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[u] = (kin && col < out) ? *(const float4 *)(W + (size_t)col * in + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < in; k0 += 32)
     {
-        // W tile: 32 rows(o) x 32 k  -> 1024 elements, 4 per thread
-        for (int i = tid; i < 1024; i += 256)
-        {
-            const int r = i >> 5, k = i & 31;
-            const int o = o0 + r, kk = k0 + k;
-            Wt[r][k] = (o < out && kk < in) ? W[(size_t)o * in + kk] : 0.f;
-        }
-        for (int i = tid; i < 512; i += 256)
-        {
-            const int r = i >> 5, k = i & 31;
-            const int nn = n0 + r, kk = k0 + k;
-            Xt[r][k] = (nn < n && kk < in) ? x[(size_t)nn * ldx + kk] : 0.f;
-        }
-        __syncthreads();
+        __syncthreads();                                       // previous chunk fully consumed
 #pragma unroll
-        for (int k = 0; k < 32; k++)
+        for (int u = 0; u < 4; u++)
         {
-            const float w = Wt[ol][k];
-            acc0 = fmaf(w, Xt[nl][k], acc0);
-            acc1 = fmaf(w, Xt[nl + 8][k], acc1);
+            const int idx = lane + u * 64, r = idx >> 3, c = (idx & 7) * 4;
+            Xs[r][c] = xv[u].x; Xs[r][c + 1] = xv[u].y; Xs[r][c + 2] = xv[u].z; Xs[r][c + 3] = xv[u].w;
+            Ws[r][c] = wv[u].x; Ws[r][c + 1] = wv[u].y; Ws[r][c + 2] = wv[u].z; Ws[r][c + 3] = wv[u].w;
         }
         __syncthreads();
+        if (k0 + 32 < in) fetch(k0 + 32);                      // next chunk's rows are in flight under this chunk's MFMAs
+#pragma unroll
+        for (int k = 0; k < 32; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[i][k + kk], Ws[i][k + kk], acc, 0, 0, 0);
     }
-    const int o = o0 + ol;
-    if (o >= out) return;
-    const float bias = b ? b[o] : 0.f;
-    const float ex = extra ? extra[o] : 0.f;
-    if (n0 + nl < n)
+    // D: col = lane&31 (output), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (token)
+    const int col = o0 + i;
+    if (col >= out) return;
+    const float bias = b ? b[col] : 0.f;
+    const float ex = extra ? extra[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
     {
-        float v = acc0 + bias;
-        if (extra) v = v + ex;
-        y[(size_t)(n0 + nl) * ldy + o] = v;
-    }
-    if (n0 + nl + 8 < n)
-    {
-        float v = acc1 + bias;
-        if (extra) v = v + ex;
-        y[(size_t)(n0 + nl + 8) * ldy + o] = v;
+        const int t = n0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (t < n)
+        {
+            float v = acc[r] + bias;
+            if (extra) v = v + ex;
+            y[(size_t)t * ldy + col] = v;
+        }
     }
 }
 
 hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int n, int in, const float *W, const float *b, int out,
                          float *y, int ldy, const float *extra)
 {
-    hipLaunchKernelGGL(linear_kernel, dim3((out + 31) / 32, (n + 15) / 16), dim3(256), 0, s, x, ldx, n, in, W, b, out, y,
+    if ((in & 3) || (ldx & 3)) return hipErrorInvalidValue;          // float4 row loads
+    hipLaunchKernelGGL(linear_mfma_kernel, dim3((out + 31) / 32, (n + 31) / 32), dim3(64), 0, s, x, ldx, n, in, W, b, out, y,
                        ldy, extra);
     return hipGetLastError();
 }
