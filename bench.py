@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[2]/[3] extras (used under rocprofv3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +172,8 @@ def main():
         #   configs[2] full chain phoneme -> wav, 128 phonemes, T = 512, batch 1 (host buffers in/out)
         #   configs[3] batch of 32 mixed-length utterances (32..256 phonemes), T = 1024 each, 4 in-flight lanes
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped (--no-extras)")
             from zerovox_cpp_amd import sharding
             model.set_graph_mode(False)
             ids, puncts, style = synth.encoder_inputs(g, 5, 128)

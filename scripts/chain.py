@@ -20,6 +20,15 @@ for _ in range(R):
     wav, nf = m.synthesize(ids, puncts, style, T)
 dt = (time.perf_counter() - t0) / R
 print(f"synthesize N={N} T={T}: {dt*1e3:.3f} ms/utt (host buffers, eager) -> {T*300/22050/dt:.0f} xRT, frames {nf}")
+m.set_graph_mode(True)
+for _ in range(3):
+    wavg, nfg = m.synthesize(ids, puncts, style, T)
+t0 = time.perf_counter()
+for _ in range(R):
+    wavg, nfg = m.synthesize(ids, puncts, style, T)
+dtg = (time.perf_counter() - t0) / R
+m.set_graph_mode(False)
+print(f"synthesize N={N} T={T}: {dtg*1e3:.3f} ms/utt (host buffers, hipGraph replay) -> {T*300/22050/dtg:.0f} xRT, same bits as eager: {bool((wavg == wav).all() and nfg == nf)}")
 m.profile_begin()
 for _ in range(5):
     m.synthesize(ids, puncts, style, T)

@@ -180,17 +180,17 @@ static void synthesize_enqueue(Model &M, const int32_t *ids, const int32_t *punc
     const size_t b_ids = al((size_t)n * 4), b_sty = al(E * 4), b_hid = al((size_t)T * E * 4), b_mel = al((size_t)T * Mm * 4),
                  b_wav = al((size_t)T * hop * 4);
     M.reserve(n, T);
-    char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + b_mel + b_wav);
+    char *io = (char *)M.io_scratch(256 + 2 * b_ids + b_sty + b_hid + b_mel + b_wav);
+    int32_t *d_nf = (int32_t *)io;
+    io += 256;
     int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
     float *d_sty = (float *)(io + 2 * b_ids), *d_hid = (float *)(io + 2 * b_ids + b_sty);
     float *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
     ZV_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
     ZV_HIP(hipMemcpyAsync(d_pun, puncts, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
     ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
-    Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
-    ZV_HIP(hipMemcpyAsync(nf_host, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
-    M.decode_dev(d_hid, d_sty, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
-    M.vocode_dev(d_mel, T, d_wav);
+    M.chain_dev(d_ids, d_pun, d_sty, n, T, d_hid, d_mel, d_wav, d_nf);
+    ZV_HIP(hipMemcpyAsync(nf_host, d_nf, 4, hipMemcpyDeviceToHost, M.stream));
     ZV_HIP(hipMemcpyAsync(wav, d_wav, (size_t)T * hop * 4, hipMemcpyDeviceToHost, M.stream));
 }
 

@@ -793,6 +793,56 @@ void Model::drop_graphs()
     for (auto &g : graphs_)
         if (g.exec) hipGraphExecDestroy(g.exec);
     graphs_.clear();
+    for (auto &g : chain_graphs_)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    chain_graphs_.clear();
+}
+
+void Model::chain_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
+                      float *d_hidden, float *d_mel, float *d_wav, int32_t *d_nframes)
+{
+    auto run = [&]() {
+        EncoderTaps t = encode_dev(d_ids, d_puncts, d_style, N, T, d_hidden);
+        ZV_HIP(hipMemcpyAsync(d_nframes, t.n_frames, 4, hipMemcpyDeviceToDevice, stream));
+        decode_dev(d_hidden, d_style, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
+        vocode_dev(d_mel, T, d_wav);
+    };
+    if (!graph_mode || profiling || cur_lane_ != 0)
+    {
+        run();
+        return;
+    }
+    const void *key[7] = {d_ids, d_puncts, d_style, d_hidden, d_mel, d_wav, d_nframes};
+    for (auto &g : chain_graphs_)
+        if (g.N == N && g.T == T && memcmp(g.p, key, sizeof(key)) == 0)
+        {
+            ZV_HIP(hipGraphLaunch(g.exec, stream));
+            return;
+        }
+    arena_require(arena_bytes_for(N, T));        // hipMalloc is not capturable
+    hipGraph_t graph = nullptr;
+    ZV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try
+    {
+        run();
+    }
+    catch (...)
+    {
+        hipStreamEndCapture(stream, &graph);
+        if (graph) hipGraphDestroy(graph);
+        throw;
+    }
+    ZV_HIP(hipStreamEndCapture(stream, &graph));
+    ChainGraph cg;
+    cg.N = N;
+    cg.T = T;
+    memcpy(cg.p, key, sizeof(key));
+    hipError_t e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) fail(ZV_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    if (chain_graphs_.size() >= 16) drop_graphs();
+    chain_graphs_.push_back(cg);
+    ZV_HIP(hipGraphLaunch(cg.exec, stream));
 }
 
 void Model::vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav)

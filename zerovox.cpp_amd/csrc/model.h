@@ -46,6 +46,13 @@ struct ProfEntry
     double      bytes, flops;
 };
 
+struct ChainGraph
+{
+    uint32_t       N = 0, T = 0;
+    const void    *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t exec = nullptr;
+};
+
 struct VocoderGraph
 {
     uint32_t        T = 0;
@@ -96,6 +103,11 @@ class Model
     // graph replay of the vocoder schedule
     bool graph_mode = false;
     void vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav);
+    // encoder -> decoder -> vocoder back to back (graph replay keyed by (N, T, buffers) when graph_mode is on)
+    // d_nframes (device, 4 bytes, outside the arena) receives the regulator's frame count: the encoder's tap area is
+    // recycled by the decoder
+    void chain_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
+                   float *d_hidden, float *d_mel, float *d_wav, int32_t *d_nframes);
 
     // profiling (HIP events around every launch while enabled)
     bool profiling = false;
@@ -195,6 +207,7 @@ class Model
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     std::vector<VocoderGraph> graphs_;
+    std::vector<ChainGraph> chain_graphs_;
     void drop_graphs();
 };
 
