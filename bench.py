@@ -64,10 +64,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible — the HIP path has no CPU fallback")
+    # rehearsal hook: ZV_BENCH_ONE_GPU=1 puts every rank on cuda:0 with the gloo backend, so the N > 1 code path
+    # (barrier, max-over-ranks, rank-0 JSON) can be exercised on a one-GPU box; never set by the driver
+    one_gpu = os.environ.get("ZV_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     load_package()
     from zerovox_cpp_amd import capi, gguf, synth
@@ -107,7 +115,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -1,4 +1,2 @@
 export TMPDIR=/tmp
-for v in 0 1 2 4 3 5 6 7; do echo "== ZV_DBG=$v"; ZV_DBG=$v python bench.py --steps 50 --no-cpu-baseline --no-graph 2>/dev/null | python -c "
-import json,sys
-j=json.loads(sys.stdin.read()); print(j['ms_per_step'], [(k['name'], round(k['avg_us'],1)) for k in j['extra']['kernels']])"; done
+for v in 5 13 0 8; do echo "== ZV_DBG=$v"; ZV_DBG=$v ZEROVOX_AMD_LIB=$PWD/variants/lib_nob.so bash scripts/prof.sh A=1 | grep -E "pair" | awk '{print $1, $2, $NF, $(NF-1)}'; done
