@@ -31,15 +31,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-static constexpr int CK_MAX = 128;
+static constexpr int CK_MAX = 256;
 #ifndef ZV_STAGE_U
 #define ZV_STAGE_U 4
 #endif
 
-int conv_pick_ck(int Cin_p)
+int conv_pick_ck(int Cin_p, int ck_max)
 {
-    // full 128-channel chunks (they run on the immediate-address MFMA loop) + one remainder chunk
-    return Cin_p < CK_MAX ? Cin_p : CK_MAX;
+    if (ck_max <= 0 || ck_max > CK_MAX) ck_max = CK_MAX;
+    // full 256-channel chunks (they run on the immediate-address MFMA loop; fewer stage/barrier rounds per conv)
+    // + one remainder chunk
+    return Cin_p < ck_max ? Cin_p : ck_max;
 }
 
 size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K)
@@ -370,7 +372,16 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
             const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
             // full chunks of 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there and
             // the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
-            if (ck == 128 && J.ck == 128)
+            // (the 256-channel instantiation is kept to MT = 1: with taller tiles it pushed the whole kernel to 176 VGPRs)
+            bool done256 = false;
+            if constexpr (MT == 1)
+                if (ck == 256 && J.ck == 256)
+                {
+                    mfma_taps<256, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
+                    done256 = true;
+                }
+            if (done256) {}
+            else if (ck == 128 && J.ck == 128)
                 mfma_taps<128, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
             else if (ck == 64 && J.ck == 64)
                 mfma_taps<64, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
@@ -469,6 +480,7 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
     };
     int MT = 4;
     while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
+    while (MT > 1 && (size_t)(32 * MT * (4 / WN) + halo + dmax) * (ck * 2 + 16) > 80 * 1024) MT >>= 1;   // keep >= 2 workgroups per CU in LDS
     {   // experiment hook: ZV_CONV_MT=<min MT> / ZV_CONV_WGS=<target workgroups per CU * 100>
         static const char *e_mt = getenv("ZV_CONV_MT");
         static const char *e_w = getenv("ZV_CONV_WGS");

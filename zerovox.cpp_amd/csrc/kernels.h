@@ -66,7 +66,8 @@ struct ConvJobs
 
 // bytes of one packed conv weight: [ntile32][chunk][tap][kc][lane 64][8 halfs]
 size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K);
-int    conv_pick_ck(int Cin_p);
+// input-channel chunk per LDS pass: min(Cin_p, ck_max); ck_max <= 0 means the kernel's maximum (256)
+int    conv_pick_ck(int Cin_p, int ck_max = 0);
 // host-side repack of a GGUF conv weight (ggml ne [K, IC, OC], f16, k fastest) into fragment order
 void   pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, int ck, uint16_t *dst);
 // all jobs of one launch share L-extent class, Cout_p and tile configuration

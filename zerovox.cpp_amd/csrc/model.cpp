@@ -106,7 +106,7 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
     const int OCp = round_up(OC, 16);
     c.Cout = s * OCp;
     c.Cout_p = s * OCp;
-    c.ck = conv_pick_ck(c.Cin_p);
+    c.ck = conv_pick_ck(c.Cin_p, 128);      // measured: the 3-input (MRF mean) prologue of these convs prefers 128-channel chunks
     // virtual weight in GGUF conv layout [OC'][IC][K'] (k fastest)
     std::vector<uint16_t> v((size_t)c.Cout * IC * c.K, 0);
     const uint16_t *src = (const uint16_t *)w.data;
