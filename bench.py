@@ -162,7 +162,8 @@ def main():
                     "avg_launch_us": round(1e3 * rb["total_ms"] / rb["launches"], 2),
                     "launches_per_step": rb["launches"] // psteps,
                     "mfma_TFLOPs": round(rb["algo_flops"] / (rb["total_ms"] * 1e-3) / 1e12, 1),
-                    "timing": "hipEvent pairs around every launch on the model's stream (eager), %d steps" % psteps}
+                    "timing": "hipEvent pair around each stage's run of consecutive ResBlock launches on the model's stream "
+                              "(eager, 3-6 launches per pair), %d steps" % psteps}
 
     # ---- PCIe-inclusive rate (host mel in, host wav out) — reported, never `value` ----
     extra = {}

@@ -369,7 +369,7 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
                 it = agg.emplace(p.name, s).first;
                 order.push_back(p.name);
             }
-            it->second.launches++;
+            it->second.launches += (uint32_t)p.launches;
             it->second.total_ms += ms;
             it->second.algo_bytes += p.bytes;
             it->second.algo_flops += p.flops;

@@ -567,7 +567,7 @@ void Model::prof_clear()
 void Model::tick(const char *, double, double, hipEvent_t *e0)
 {
     *e0 = nullptr;
-    if (!profiling) return;
+    if (!profiling || in_group_) return;
     ZV_HIP(hipEventCreate(e0));
     ZV_HIP(hipEventRecord(*e0, stream));
 }
@@ -575,10 +575,37 @@ void Model::tick(const char *, double, double, hipEvent_t *e0)
 void Model::tock(hipEvent_t e0, const char *name, double bytes, double flops)
 {
     if (!profiling) return;
+    if (in_group_)
+    {
+        group_bytes_ += bytes;
+        group_flops_ += flops;
+        group_n_++;
+        return;
+    }
     hipEvent_t e1;
     ZV_HIP(hipEventCreate(&e1));
     ZV_HIP(hipEventRecord(e1, stream));
-    prof.push_back({name, e0, e1, bytes, flops});
+    prof.push_back({name, e0, e1, bytes, flops, group_n_ > 0 ? group_n_ : 1});
+}
+
+// the ResBlock launches of one stage run back to back: one event pair brackets the whole run so that the per-launch
+// average is not inflated by ~2 us of event-record overhead per launch
+void Model::group_begin()
+{
+    if (!profiling) return;
+    ZV_HIP(hipEventCreate(&group_e0_));
+    ZV_HIP(hipEventRecord(group_e0_, stream));
+    in_group_ = true;
+    group_bytes_ = group_flops_ = 0.0;
+    group_n_ = 0;
+}
+
+void Model::group_end(const char *name)
+{
+    if (!profiling || !in_group_) return;
+    in_group_ = false;
+    tock(group_e0_, name, group_bytes_, group_flops_);
+    group_n_ = 0;
 }
 
 #define ZV_LAUNCH(name, bytes, flops, call)          \
@@ -707,6 +734,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         const bool enough_rows = Cp != 256 || (long)(L / 54) * 3 >= 2L * n_cu;
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
+        group_begin();
         for (int d = 0; d < voc_.n_dil; d++)
         {
             ConvJob j1[3], j2[3];
@@ -765,6 +793,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 conv(j2, 3, "voc_resblock_conv", b2, f2);
             }
         }
+        group_end("voc_resblock_conv");
         for (int jb = 0; jb < 3; jb++) y[jb] = const_cast<float *>(ycur[jb]);
         for (int jb = 0; jb < 3; jb++) prev_y[jb] = y[jb];
     }

@@ -44,6 +44,7 @@ struct ProfEntry
     const char *name;
     hipEvent_t  e0, e1;
     double      bytes, flops;
+    int         launches;       // consecutive launches of the same family bracketed by this event pair
 };
 
 struct ChainGraph
@@ -191,6 +192,12 @@ class Model
     ConvJob job(const ConvW &w, int L) const;
     void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
     void tock(hipEvent_t e0, const char *name, double bytes, double flops);
+    void group_begin();
+    void group_end(const char *name);
+    bool       in_group_ = false;
+    hipEvent_t group_e0_ = nullptr;
+    double     group_bytes_ = 0.0, group_flops_ = 0.0;
+    int        group_n_ = 0;
 
     struct Lane
     {
