@@ -80,7 +80,7 @@ __device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : 
 // ---- stage: HBM -> prologue -> f16 -> LDS.  U independent 16-byte loads per thread are issued before any of
 // them is consumed (hipcc otherwise waits vmcnt(0) after every load and the tile fill becomes a chain of
 // full HBM latencies).  LDS row r holds input time row_t0 + r; out-of-range rows are zeros.
-template <int U, int PRO>
+template <int U, int PRO, int NTH = 256>
 __device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
                                              int tid)
 {
@@ -89,8 +89,8 @@ __device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int R
     const int L = J.L;
     constexpr int pro = PRO;
     int r = tid / cols, c4 = tid - r * cols;
-    const int dr = 256 / cols, dc = 256 - dr * cols;
-    for (int base = tid; base < total; base += 256 * U)
+    const int dr = NTH / cols, dc = NTH - dr * cols;
+    for (int base = tid; base < total; base += NTH * U)
     {
         float4 v[U], v1[U], v2[U];
         half4 hraw[U];
@@ -99,7 +99,7 @@ __device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int R
 #pragma unroll
         for (int u = 0; u < U; u++)
         {
-            live[u] = base + u * 256 < total;
+            live[u] = base + u * NTH < total;
             const int t = row_t0 + r;
             inr[u] = live[u] && t >= 0 && t < L;
             lofs[u] = r * RS + c4 * 8;
@@ -180,17 +180,17 @@ __device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int R
     }
 }
 
-template <int U>
+template <int U, int NTH = 256>
 __device__ __forceinline__ void stage_tile(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
                                            int tid)
 {
     switch (J.pro)      // wave-uniform; each case is a straight-line batched fill
     {
-        case PRO_RAW_F16: stage_tile_p<U, PRO_RAW_F16>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
-        case PRO_ACT: stage_tile_p<U, PRO_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
-        case PRO_NORM_ACT: stage_tile_p<U, PRO_NORM_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
-        case PRO_MELNORM: stage_tile_p<U, PRO_MELNORM>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
-        default: stage_tile_p<U, PRO_SUM3_ACT>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_RAW_F16: stage_tile_p<U, PRO_RAW_F16, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_ACT: stage_tile_p<U, PRO_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_NORM_ACT: stage_tile_p<U, PRO_NORM_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_MELNORM: stage_tile_p<U, PRO_MELNORM, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        default: stage_tile_p<U, PRO_SUM3_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
     }
 }
 
@@ -262,13 +262,16 @@ __device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT][NT], const half8 (
 // one step ahead.  All LDS and weight addresses inside a body are immediates off the body's base.  A wave covers
 // NT output tiles of 32 channels (their weight segments are `wseg` half8 apart) and MT row tiles.
 template <int CP, int MT, int NT, bool SWAP>
-__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
+__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K,
+                                          int ib0 = 0, int ib1 = -1)
 {
+    // [ib0, ib1): the bodies this wave runs (split-K callers hand every wave a slice and pass ap / wq already
+    // advanced to body ib0); the default is the whole contraction
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;        // taps per body: 4 / 2 / 1 / (1/2) for CP = 32 / 64 / 128 / 256
     constexpr bool HALF = NKC == 16;                     // CP = 256: a tap is two bodies (channels 0-127, 128-255)
     const int nsb = (K * NKC + 3) >> 2;                  // 4-step sub-blocks (the last one may run partly on zero weights)
-    const int nb = nsb >> 1;
+    const int nb = ib1 < 0 ? (nsb >> 1) : ib1;
     half8 b0[4][NT], b1[4][NT];
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -285,7 +288,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
         const char *np_ = ZV_A_ADDR(un);                                                     \
         _Pragma("unroll") for (int mt = 0; mt < MT; mt++) dst[mt] = *(const half8 *)(np_ + mt * 32 * RS); \
     }
-    for (int ib = 0; ib < nb; ib++)
+    for (int ib = ib0; ib < nb; ib++)
     {
         const char *tb[4];
         tb[0] = ap;
@@ -313,7 +316,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
         ap = apn;
         wq += 8 * 64;
     }
-    if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
+    if (ib1 < 0 && (nsb & 1))                    // odd sub-block count (CP = 64): one more tap on b0
     {
         const char *tb[4] = {ap, ap, ap, ap};
         const char *apn = ap;
@@ -326,6 +329,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 #undef ZV_LOAD_A
 #undef ZV_A_ADDR
 }
+
 
 template <int MT, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
@@ -430,6 +434,141 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     }
 }
 
+// ---- split-K variant for short sequences.  A conv over T = 512 decoder frames has 16 x 33 output tiles of 32 x 32:
+// the plain kernel gives that 144 workgroups, most CUs run one wave per SIMD and that wave waits out every LDS and
+// L2 latency of its (tap, channel) chain alone.  Here a workgroup of NWV waves owns BM = 32*MT rows x NW output
+// tiles of ONE job; the KS = NWV / NW waves that share a tile split the contraction of every 256-channel chunk, the
+// partial sums meet in LDS (fixed order: deterministic) and each of the KS waves finishes 1/KS of the tile's rows
+// (bias, residual, activation, store).  NW is chosen per job by the launcher from the jobs' shapes only (never from
+// L: the summation order of an output element must not depend on the utterance length) so that the workgroups of
+// unequal jobs stream about the same number of weight bytes.
+// Measured (profiles/r01_v5_*): decoder chain 1.98 -> 1.84 ms.  HiFi-GAN stage 1 (2 560 rows, jobs of 3 / 7 / 11
+// taps) does NOT gain: there the plain kernel's 480 workgroups are bound by the matrix pipe at the clock the chip
+// holds under MFMA load plus the imbalance between the 3-tap and 11-tap workgroups (phase ablation: MFMA phase 9.7 us
+// whether the weights come from L2 or sit in L1, with 4 or 8 waves per tile, MT = 1 or 2), so it stays on the plain
+// kernel.
+template <int NWV, int MT>
+__global__ __launch_bounds__(64 * NWV) void conv1d_splitk_kernel(const ConvJobs jobs)
+{
+    constexpr int NTH = 64 * NWV, BM = 32 * MT, NR = 16 * MT;
+    const ConvJob &J = jobs.j[blockIdx.z];
+    const int L = J.L;
+    const int m0 = blockIdx.x * BM;
+    const int lg_nw = J.sk_lg_nw, NW = 1 << lg_nw, KS = NWV >> lg_nw;
+    const int Cout_p = J.Cout_p;
+    const int ntiles = (Cout_p + 31) >> 5;
+    if (m0 >= L || (int)(blockIdx.y << lg_nw) >= ntiles) return;      // grid.y is sized for the job with the smallest NW
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wave >> lg_nw, wn = wave & (NW - 1);
+
+    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p;
+    const int nicb = Cin_p >> 4;
+    const int nt = (blockIdx.y << lg_nw) + wn;
+    const bool n_ok = nt < ntiles;
+    const int rows = BM + (K - 1) * dil;
+    const int RS = J.ck * 2 + 16;
+
+    floatx16 acc[MT][1];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
+    const char *abase = smem + (lane & 31) * RS + (lane >> 5) * 16;
+    const int nb = 2 * K, ib0 = ks * nb / KS, ib1 = (ks + 1) * nb / KS;      // bodies of half a tap (128 channels)
+
+    for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
+    {
+        const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
+        if (c0) __syncthreads();
+        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U, NTH>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        __syncthreads();
+        if (n_ok && !(J.dbg & 2))
+        {
+            const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
+            if (ck == 256)
+                mfma_taps<256, MT, 1, false>(acc, abase + (ib0 >> 1) * dil * RS + (ib0 & 1) * 256, dil * RS,
+                                             wp + (size_t)ib0 * 8 * 64, 0, K, ib0, ib1);
+            else if (ks == KS - 1)           // remainder chunk (< 256 channels)
+                mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
+        }
+    }
+
+    // ---- partial sums meet in LDS: red[slice][tile][register][lane]
+    __syncthreads();                          // the input tile is dead: its LDS becomes the exchange area
+    float *red = (float *)smem;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(((ks << lg_nw) + wn) * NR + mt * 16 + r) * 64 + lane] = acc[mt][0][r];
+    __syncthreads();
+    if (!n_ok || (J.dbg & 4)) return;
+
+    // ---- epilogue: wave ks finishes accumulator registers [ks*RPW, (ks+1)*RPW) of its tile, four at a time
+    const int oc = nt * 32 + (lane & 31);
+    if (oc >= Cout_p) return;
+    const float bias = J.bias ? J.bias[oc] : 0.f;
+    const float escale = J.escale;
+    const bool has_res = J.res != nullptr;
+    const int RPW = NR / KS;                  // >= 4 (launcher)
+    const float *rp = red + (wn * NR) * 64 + lane;
+    const int kstride = (NR << lg_nw) * 64;
+    for (int i0 = ks * RPW; i0 < (ks + 1) * RPW; i0 += 4)
+    {
+        int t[4];
+        float resv[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int idx = i0 + i, r = idx & 15;
+            t[i] = m0 + (idx >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            resv[i] = has_res ? J.res[(size_t)(t[i] < L ? t[i] : L - 1) * J.ldres + oc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            float sum = rp[(i0 + i) * 64];
+            for (int k = 1; k < KS; k++) sum += rp[k * kstride + (i0 + i) * 64];
+            v[i] = sum;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            if (t[i] >= L) continue;
+            float x = v[i] + bias;
+            if (has_res) x = x + resv[i];
+            x = x * escale;
+            if (J.eact) x = lrelu(x, J.oslope);
+            if (J.out_f16)
+                ((_Float16 *)J.out)[(size_t)t[i] * J.ldo + oc] = (_Float16)x;
+            else
+                ((float *)J.out)[(size_t)t[i] * J.ldo + oc] = x;
+        }
+    }
+}
+
+template <int NWV, int MT>
+static hipError_t launch_splitk_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int ny, int halo, int ck, int dmax_)
+{
+    constexpr int BM = 32 * MT;
+    dim3 grid((Lmax + BM - 1) / BM, ny, njobs);
+    size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);
+    const size_t red = (size_t)NWV * MT * 16 * 64 * 4;
+    if (red > lds) lds = red;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = conv1d_splitk_kernel<NWV, MT>;
+    if (lds > 64 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, jobs);
+    return hipGetLastError();
+}
+
 template <int MT, int WN>
 static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int K, int dil, int ck, int dmax_)
 {
@@ -491,6 +630,45 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
             while (MT > 1 && wgs(MT) < tgt) MT >>= 1;
         }
         if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
+    }
+    {   // short sequences over 256-channel chunks: conv1d_splitk_kernel, workgroup shapes balanced per job
+        const int e_sk = getenv("ZV_SPLITK") ? atoi(getenv("ZV_SPLITK")) : -1;      // 0 = off, else MT (1 | 2)
+        const int e_lg = getenv("ZV_SPLITK_LG") ? atoi(getenv("ZV_SPLITK_LG")) : 0;       // coarser workgroup shapes (A/B)
+        bool ok = ck == 256 && ntiles >= 4;
+        for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256;
+        // measured (MI355X, medium geometry): the decoder's 512-row convs (144 plain workgroups) run 7 % faster per
+        // chain on the split kernel, HiFi-GAN stage 1 (480 plain workgroups, three unequal jobs) does not
+        int smt = (ok && wgs(1) < (long)n_cu) ? 1 : 0;
+        if (e_sk >= 0 && ok) smt = e_sk;
+        if (smt == 1 || smt == 2)
+        {
+            constexpr int NWV = 8;
+            const int lg_min = smt == 1 ? 1 : 0;             // the epilogue hands each wave >= 4 accumulator registers
+            // Output tiles per workgroup, per job: the heaviest job (most weight bytes per tile) gets one tile per
+            // workgroup and all 8 waves on its contraction, lighter jobs the power of two that brings their
+            // workgroups closest to the same weight traffic.  A function of the jobs' shapes only, never of L: the
+            // summation order of an output element must not depend on the utterance length.
+            int lg[CONV_MAX_JOBS];
+            long cmax = 0;
+            for (int i = 0; i < njobs; i++) cmax = std::max(cmax, (long)jobs[i].K * jobs[i].Cin_p);
+            for (int i = 0; i < njobs; i++)
+            {
+                const double ratio = (double)cmax / ((double)jobs[i].K * jobs[i].Cin_p);
+                int l = lg_min + e_lg;
+                while (l < 3 && ratio >= 1.4142135623730951 * (double)(1 << (l - lg_min - e_lg))) l++;
+                lg[i] = l > 3 ? 3 : l;
+            }
+            int ny = 1;
+            for (int i = 0; i < njobs; i++)
+            {
+                js.j[i].sk_lg_nw = lg[i];
+                const int y = (ntiles + (1 << lg[i]) - 1) >> lg[i];
+                ny = y > ny ? y : ny;
+            }
+            for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i].sk_lg_nw = lg[0];
+            if (smt == 1) return launch_splitk_cfg<NWV, 1>(s, js, njobs, Lmax, ny, halo, ck, dmax);
+            return launch_splitk_cfg<NWV, 2>(s, js, njobs, Lmax, ny, halo, ck, dmax);
+        }
     }
 #define ZV_CASE(mt, wn) \
     if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, Kh, 1, ck, dmax);
@@ -610,6 +788,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;        // half8 units per n-tile segment
+
 
     // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)P.y, 0, L * CP * 4, 0x00020000);

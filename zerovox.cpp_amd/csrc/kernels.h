@@ -56,6 +56,7 @@ struct ConvJob
     void        *out;
     int          ldo;
     int          dbg;            // timing-only ablation bits (ZV_DBG env): 1 no staging loads, 2 no MFMA, 4 no epilogue
+    int          sk_lg_nw;       // split-K kernel: log2(output tiles per workgroup), filled in by launch_conv
 };
 
 constexpr int CONV_MAX_JOBS = 4;
