@@ -130,3 +130,28 @@ def test_synthetic_checkpoint_is_deterministic():
 
 
 PINNED_TINY_SHA256 = "b7573a897ac23670e07dd746b9e3be836911ebd22bd02463eeefe2853c457d68"
+
+
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zerovox.cpp_amd", "zerovox")
+
+
+def test_cli_help_info_and_loud_failure(tmp_path):
+    """`zerovox` is the counterpart of the reference's main (src/zerovox.cpp:396-406): same defaults, plus flags.
+    Without a GPU it must list a checkpoint (--info needs no device) and fail loudly on synthesis."""
+    import subprocess
+    import torch
+    from zerovox_cpp_amd import synth
+    assert os.access(CLI, os.X_OK), "run __graft_entry__.build() first"
+    r = subprocess.run([CLI, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "medium-ldec.gguf" in r.stdout and "foo.wav" in r.stdout
+    r = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
+    p = str(tmp_path / "t.gguf")
+    synth.write_checkpoint(p, synth.TINY, 5)
+    r = subprocess.run([CLI, "-m", p, "--info"], capture_output=True, text=True)
+    assert r.returncode == 0 and "hifigan.mean" in r.stdout and "sinusoid_encoding_table" in r.stdout
+    r = subprocess.run([CLI, "-m", str(tmp_path / "missing.gguf"), "--info"], capture_output=True, text=True)
+    assert r.returncode == 1 and "zerovox:" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([CLI, "-m", p, "-o", str(tmp_path / "o.wav")], capture_output=True, text=True)
+        assert r.returncode == 1 and "zerovox:" in r.stderr and not os.path.exists(tmp_path / "o.wav")

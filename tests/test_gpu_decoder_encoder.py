@@ -142,3 +142,36 @@ def test_synthesize_batch_equals_per_utterance(models):
         assert nf == nf_ref and wav.shape == ref.shape
         assert np.array_equal(wav, ref)
     assert model.synthesize_batch([]) == []
+
+
+def test_cli_writes_the_same_wav(models, ckpt, tmp_path):
+    """the `zerovox` binary (facade + C-ABI, like the reference's main) must write exactly the PCM16 samples that
+    zv_synthesize + zv_write_wav produce for the same utterance; --trim cuts at the regulator's frame count"""
+    import os
+    import subprocess
+    from zerovox_cpp_amd import capi, synth
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zerovox.cpp_amd", "zerovox")
+    model, g, tensors = models("small")
+    path, _, _ = ckpt("small")
+    N = 24
+    ids, puncts, style = synth.encoder_inputs(g, 5, N)
+    utt = tmp_path / "utt.txt"
+    utt.write_text(" ".join(map(str, ids.tolist())) + "\n" + " ".join(map(str, puncts.tolist())) + "\n" +
+                   " ".join(repr(float(x)) for x in style.tolist()) + "\n")
+    out = tmp_path / "cli.wav"
+    r = subprocess.run([cli, "-m", path, "-u", str(utt), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    T = g.max_seq_len
+    wav, nf = model.synthesize(ids, puncts, style, T)
+    ref = tmp_path / "ref.wav"
+    capi.write_wav(str(ref), wav, g.sampling_rate)
+    assert out.read_bytes() == ref.read_bytes()
+    assert f"{T * g.hop_size} samples" in r.stdout
+    r = subprocess.run([cli, "-m", path, "-u", str(utt), "-o", str(out), "--trim"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    capi.write_wav(str(ref), wav[: nf * g.hop_size], g.sampling_rate)
+    assert out.read_bytes() == ref.read_bytes() and 0 < nf <= T
+    # the no-argument form of the reference's main: default model name in the working directory, foo.wav out
+    os.symlink(path, tmp_path / "medium-ldec.gguf")
+    r = subprocess.run([cli], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and (tmp_path / "foo.wav").stat().st_size == 44 + 2 * T * g.hop_size

@@ -3,4 +3,4 @@
 The directory name contains a dot (it mirrors the reference's repo name), so it is loaded through
 `__graft_entry__.load_package()` under the module name `zerovox_cpp_amd`.
 """
-from . import gguf, sharding, synth  # noqa: F401
+from . import convert, gguf, sharding, synth  # noqa: F401
