@@ -175,3 +175,68 @@ def test_cli_writes_the_same_wav(models, ckpt, tmp_path):
     os.symlink(path, tmp_path / "medium-ldec.gguf")
     r = subprocess.run([cli], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0 and (tmp_path / "foo.wav").stat().st_size == 44 + 2 * T * g.hop_size
+
+
+def test_encoder_edge_cases(models):
+    """ragged / extreme inputs the reference's eval handles (src/fs2encoder.cpp:594-656): a single phoneme, a frame
+    budget smaller than the predicted durations (truncate at T), one far larger (zero-filled tail), as many phonemes
+    as the position table has rows, one more than that (error), T = 0 (error)"""
+    from zerovox_cpp_amd import capi, synth
+    from oracle import zvoracle
+    model, g, tensors = models("tiny")
+    orc = zvoracle.Oracle(tensors)
+    # one phoneme
+    ids, puncts, style = synth.encoder_inputs(g, 9, 1)
+    e = model.encode(ids, puncts, style, 16)
+    r = orc.encoder(g, ids, puncts, style, 16)
+    assert abs(float(e["logdur"][0]) - float(r["logdur"][0])) <= 5e-3
+    hid, nf = orc.length_regulator(e["features"], e["logdur"], 16)
+    assert nf == e["n_frames"] and np.array_equal(hid, e["hidden"])
+    # truncation: 40 phonemes x ~4 frames into 8 frames; and a long zero tail
+    ids, puncts, style = synth.encoder_inputs(g, 10, 40)
+    for T in (8, 1, 64):
+        e = model.encode(ids, puncts, style, T)
+        hid, nf = orc.length_regulator(e["features"], e["logdur"], T)
+        assert nf == e["n_frames"] and np.array_equal(hid, e["hidden"]) and e["hidden"].shape == (T, g.E)
+        if T <= 8:
+            assert nf == T                                  # every frame taken
+    ids4, puncts4, style4 = synth.encoder_inputs(g, 11, 4)
+    e = model.encode(ids4, puncts4, style4, 64)
+    assert 0 < e["n_frames"] < 64 and not e["hidden"][e["n_frames"]:].any()
+    # the position table has max_seq_len + 1 rows: that many phonemes run, one more is an argument error
+    nmax = g.max_seq_len + 1
+    ids, puncts, style = synth.encoder_inputs(g, 12, nmax)
+    e = model.encode(ids, puncts, style, 32)
+    assert np.isfinite(e["features"]).all() and e["features"].shape == (nmax, g.E)
+    ids, puncts, style = synth.encoder_inputs(g, 12, nmax + 1)
+    with pytest.raises(capi.ZvError) as ei:
+        model.encode(ids, puncts, style, 32)
+    assert ei.value.status == 5
+    with pytest.raises(capi.ZvError):
+        model.encode(ids4, puncts4, style4, 0)
+    # negative and too-large punctuation ids are rejected too
+    bad = puncts4.copy()
+    bad[0] = 7
+    with pytest.raises(capi.ZvError):
+        model.encode(ids4, bad, style4, 16)
+    bad[0] = -1
+    with pytest.raises(capi.ZvError):
+        model.encode(ids4, bad, style4, 16)
+
+
+def test_decoder_edge_cases(models):
+    """T = 1 (InstanceNorm over a single frame: variance 0 -> output is the affine offset, src/stylettsdec.cpp:94-98)
+    and an all-zero hidden sequence (the regulator's zero tail) stay finite and match the oracle"""
+    from zerovox_cpp_amd import synth
+    from oracle import zvoracle
+    model, g, tensors = models("tiny")
+    orc = zvoracle.Oracle(tensors)
+    _, _, style = synth.encoder_inputs(g, 5, 4)
+    for T, fill in ((1, 1.0), (2, 1.0), (8, 0.0)):
+        hid = synth.decoder_hidden(g, 21, T, fill=fill) if fill else np.zeros((T, g.E), np.float32)
+        mel = model.decode(hid, style)
+        ref = orc.decoder(hid, style)
+        assert mel.shape == (T, g.num_mels) and np.isfinite(mel).all()
+        err = float(np.max(np.abs(mel - ref)))
+        print(f"decoder T={T} fill={fill}: max err {err:.3e}")
+        assert err <= 2e-2

@@ -59,6 +59,16 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium):
           f"reference self-noise floor at this size: max ~3e-3..4e-3, rms ~1e-3 — SURVEY.md Appx D)")
     assert np.isfinite(mel).all()
     assert _rms(d) <= 2.0e-3 and np.max(np.abs(d)) <= 1.2e-2
+    # T = 512 runs the decoder's convs on the split-K kernel; longer utterances take the plain kernel: same gates
+    os.environ["ZV_SPLITK"] = "0"
+    try:
+        mel_plain = model.decode(hid, style)
+    finally:
+        del os.environ["ZV_SPLITK"]
+    d2 = mel_plain.reshape(-1)[::s] - z["mel_samples"]
+    print(f"decoder T=512, plain conv kernel: mel err max {np.max(np.abs(d2)):.3e} rms {_rms(d2):.3e}; "
+          f"split-K vs plain rms {_rms(mel - mel_plain):.3e}")
+    assert _rms(d2) <= 2.0e-3 and np.max(np.abs(d2)) <= 1.2e-2
 
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz"])
@@ -113,3 +123,42 @@ def test_host_and_device_entry_points_agree(medium):
     model.device_free(d_mel)
     model.device_free(d_wav)
     assert np.array_equal(out, ref)
+
+
+def test_fused_256_channel_stage_vs_reference_golden(ckpt):
+    """long / batched utterances run HiFi-GAN stage 1 (256 channels) on the fused dilation-pair kernel; a single
+    512-frame utterance does not (too few rows).  ZV_FUSE256=1 forces that path at 512 frames so that it is checked
+    against the reference's own output like the default path"""
+    from zerovox_cpp_amd import capi, synth
+    path, g, tensors = ckpt("medium")
+    z = np.load(os.path.join(GOLD, "medium_T512_N64.npz"))
+    T, s = int(z["T"]), int(z["stride"])
+    mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
+    os.environ["ZV_FUSE256"] = "1"
+    try:
+        m = capi.Model(path, 0)
+    finally:
+        del os.environ["ZV_FUSE256"]
+    wav = m.vocode(mel)
+    m.close()
+    err = _rms(wav[::s] - z["wav_samples"])
+    print(f"fused 256-channel stage: wav rms err (strided vs reference) {err:.3e}")
+    assert np.isfinite(wav).all() and err <= 1e-4
+
+
+def test_vocoder_beyond_max_seq_len_and_regime_change(medium):
+    """T is a run-time argument: 2 000 frames (> max_seq_len, and long enough that stage 1 switches to the fused
+    kernel by itself).  Samples far from the cut must agree with the 512-frame run to the noise floor (the two runs
+    use different kernels for stage 1, so bit equality is not expected)"""
+    from zerovox_cpp_amd import synth
+    model, g, tensors = medium
+    T = 2000
+    mel = synth.vocoder_mel(g, tensors, 33, T)
+    long = model.vocode(mel)
+    assert long.shape == (T * 300,) and np.isfinite(long).all()
+    short = model.vocode(mel[:512])
+    n = (512 - 24) * 300
+    err = _rms(long[:n] - short[:n])
+    print(f"T=2000 vs T=512 prefix: rms {err:.3e} (signal rms {_rms(short):.3f})")
+    assert err <= 1e-4
+    assert np.array_equal(long, model.vocode(mel))        # deterministic

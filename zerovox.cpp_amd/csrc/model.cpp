@@ -143,6 +143,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) fail(ZV_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
     n_cu = prop.multiProcessorCount;
     no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
+    force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
     lanes_[0].stream = stream;
@@ -731,7 +732,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         // 256-channel stage: the fused kernel needs all 256 xt channels in one workgroup, which leaves only
         // ceil(L/54) workgroups per branch — measured slower than two unfused launches (480 workgroups) until the
         // stage has enough rows to give every CU two of them (long / batched utterances)
-        const bool enough_rows = Cp != 256 || (long)(L / 54) * 3 >= 2L * n_cu;
+        const bool enough_rows = Cp != 256 || force_fuse256_ || (long)(L / 54) * 3 >= 2L * n_cu;
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
         group_begin();
