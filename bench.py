@@ -200,6 +200,30 @@ def main():
             t1 = time.perf_counter()
             model.synthesize_batch(utts)
             extra["batch32_mixed_T1024_xrt"] = round(32 * 1024 * hop / sr / (time.perf_counter() - t1), 1)
+            # the same ResBlock kernels once a launch has many rounds of workgroups (8 192 frames in one call): the
+            # 512-frame single utterance of configs[1] is one round per launch and pays every launch's fixed
+            # latencies (dispatch, first loads, store drain) in full
+            TL = 8192
+            mel_l = np.tile(mel, (TL // T + 1, 1))[:TL]
+            d_ml, d_wl = model.device_alloc(mel_l.nbytes), model.device_alloc(TL * hop * 4)
+            model.h2d(d_ml, mel_l)
+            model.reserve(1, TL)
+            for _ in range(2):
+                model.vocode_device(d_ml, TL, d_wl)
+            model.synchronize()
+            model.profile_begin()
+            for _ in range(5):
+                model.vocode_device(d_ml, TL, d_wl)
+            st_l = model.profile_end()
+            rbl = next(s_ for s_ in st_l if s_["name"] == "voc_resblock_conv")
+            tot_l = sum(s_["total_ms"] for s_ in st_l) / 5
+            extra["long_utterance_T%d" % TL] = {
+                "resblock_algo_GBps": round(rbl["algo_bytes"] / (rbl["total_ms"] * 1e-3) / 1e9, 1),
+                "resblock_frac_of_hbm_peak": round(rbl["algo_bytes"] / (rbl["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "resblock_mfma_TFLOPs": round(rbl["algo_flops"] / (rbl["total_ms"] * 1e-3) / 1e12, 1),
+                "kernel_ms_per_pass": round(tot_l, 3), "xrt_kernel_time": round(TL * hop / sr / (tot_l * 1e-3), 1)}
+            model.device_free(d_ml)
+            model.device_free(d_wl)
         except Exception as e:      # these extras must never take the headline measurement down
             extra["extras_error"] = str(e)
 
