@@ -155,3 +155,14 @@ def test_cli_help_info_and_loud_failure(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([CLI, "-m", p, "-o", str(tmp_path / "o.wav")], capture_output=True, text=True)
         assert r.returncode == 1 and "zerovox:" in r.stderr and not os.path.exists(tmp_path / "o.wav")
+
+
+def test_loader_survives_corrupt_files_under_sanitizers():
+    """host code of the library built with -fsanitize=address,undefined (GPU ASan does not exist on this pool): the
+    GGUF loader and the WAV writer are driven with ~2 000 truncated / corrupted checkpoints and must answer each
+    with a status code — no crash, no out-of-bounds read, no leak (tests/native/host_fuzz.cpp)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "asan_host.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "no crash" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
