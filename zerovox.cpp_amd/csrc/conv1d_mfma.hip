@@ -942,6 +942,196 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Whole residual block in one launch (reference src/hifigan.cpp:99-182, all iterations of the dilation loop).
+// The narrow stages are HBM-bound: per dilation pair the fused kernel above reads y (+ halo) and writes y, i.e. the
+// block's three pairs move the tile through HBM three times.  Here a workgroup loads a tile of R = 256 rows once
+// (f32, in registers) and for every dilation d
+//     X  = f16(lrelu(Y))                    (registers -> LDS)
+//     xt = f16(lrelu(conv(X, k, d) + b1))   (MFMA, weights as the A operand; packed over X like in the pair kernel)
+//     Y += conv(xt, k, 1) + b2              (MFMA; accumulated into the f32 tile)
+// All convs run over the full tile as if it were a zero-padded sequence of R rows, so after pair d the rows within
+// the cumulative halo of a tile edge are wrong — they never reach the TM = R - 2*H centre rows that are stored
+// (H = h2 * (sum(dil) + n_dil), h2 = (k-1)/2).  Rows outside [0, L) are forced to zero after every pair: they are the
+// reference's zero padding, not computed values.  Same operations in the same order per output element as the pair
+// kernel, hence the same bits.
+// LDS: X/XT region rows [0, R + 2*XM + slack), row XM + i <-> tile row i (XM = h2 * max(dil): zero margins, written
+// once).  The f32 tile itself stays in registers (see below).
+template <int CP, int MT>
+__global__ __launch_bounds__(64 * (8 / MT)) void resblock_triple_kernel(const TripleJobs jobs)
+{
+    // 8 / MT waves, each owns 32*MT tile rows x all CP (= 32) channels; its slice of the f32 tile Y lives in 16*MT
+    // registers per lane in the MFMA accumulator layout (row = (r&3) + 8*(r>>2) + 4*(lane>>5), channel = lane & 31)
+    // for the whole kernel, so LDS only holds the f16 operand tile (26 KiB: several workgroups per CU).  Every wave
+    // streams the same weight fragments (one output tile), MT row tiles per fragment.
+    constexpr int R = 256, NWV = 8 / MT, NTH = 64 * NWV;
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    static_assert(CP == 32, "one 32-channel output tile per wave");
+    const TripleJob &P = jobs.j[blockIdx.z];
+    const int L = P.L, K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int sumd = 0, dmax = 1;
+    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+    const int H = h2 * (sumd + nd);
+    const int TM = R - 2 * H;
+    const int t0 = blockIdx.x * TM;
+    if (t0 >= L) return;
+    const int XM = h2 * dmax;
+    const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;
+    const int col = lane & 31;
+    const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
+
+    // ---- zero the X region (its margins stay zero for the whole kernel); load this lane's slice of the tile:
+    // tile row i <-> time t0 - H + i, rows outside [0, L) are out of the descriptor's range and read as 0
+    for (int i = tid; i < xrows * RS / 16; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+    float yreg[MT][16];
+    {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)P.y, 0, L * CP * 4, 0x00020000);
+        const int voff = ((t0 - H + irow0) * CP + col) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                yreg[mt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, voff + (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
+    }
+
+    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
+    const float sl = P.slope;
+    for (int d = 0; d < nd; d++)
+    {
+        const int dil = P.dil[d], h1 = h2 * dil;
+        __syncthreads();                       // zero fill done / previous conv2 done reading XT
+        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
+        {
+            char *xp = smem + (XM + irow0) * RS + col * 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    *(_Float16 *)(xp + (mt * 32 + (r & 3) + 8 * (r >> 2)) * RS) = (_Float16)lrelu_max(yreg[mt][r], sl);
+        }
+        __syncthreads();
+
+        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
+        floatx16 acc[MT][1];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
+        if (!(P.dbg & 2))
+            mfma_taps<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K);
+        __syncthreads();                       // every wave is done reading X: the region becomes XT
+        {
+            const int hh = lane >> 5;
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1[d] + 8 * q + 4 * hh);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+            {
+                const int i = wave * 32 * MT + mt * 32 + (lane & 31);
+                const int t = t0 - H + i;
+                const bool in = t >= 0 && t < L;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    half4 h;
+                    h[0] = (_Float16)lrelu_max(acc[mt][0][4 * q + 0] + bq[q].x, sl);
+                    h[1] = (_Float16)lrelu_max(acc[mt][0][4 * q + 1] + bq[q].y, sl);
+                    h[2] = (_Float16)lrelu_max(acc[mt][0][4 * q + 2] + bq[q].z, sl);
+                    h[3] = (_Float16)lrelu_max(acc[mt][0][4 * q + 3] + bq[q].w, sl);
+                    uint2 pk = *(uint2 *)&h;
+                    pk.x = in ? pk.x : 0u;
+                    pk.y = in ? pk.y : 0u;
+                    *(uint2 *)(smem + (XM + i) * RS + (8 * q + 4 * hh) * 2) = pk;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
+        if (!(P.dbg & 2))
+            mfma_taps<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K);
+        {
+            const float bias = P.b2[d][col];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const int t = t0 - H + irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = (acc[mt][0][r] + bias) + yreg[mt][r];
+                    yreg[mt][r] = (t >= 0 && t < L) ? v : 0.f;
+                }
+        }
+    }
+
+    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
+    if (P.dbg & 4) return;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)P.out, 0, L * CP * 4, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int i = irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int t = t0 - H + i;
+            const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, 0);
+        }
+}
+
+bool triple_supported(int Cp, int K, const int *dil, int n_dil)
+{
+    if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || (K & 1) == 0) return false;
+    int sumd = 0;
+    for (int d = 0; d < n_dil; d++) sumd += dil[d];
+    return 256 - (K - 1) * (sumd + n_dil) >= 96;          // at least 3/8 of the tile's rows are output
+}
+
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu)
+{
+    (void)n_cu;
+    if (njobs < 1 || njobs > PAIR_MAX_JOBS) return hipErrorInvalidValue;
+    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
+    TripleJobs js;
+    int gx = 1;
+    size_t lds = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        js.j[i] = jobs[i];
+        js.j[i].dbg = dbg;
+        const TripleJob &P = jobs[i];
+        if (P.Cp != jobs[0].Cp || !triple_supported(P.Cp, P.K, P.dil, P.n_dil)) return hipErrorInvalidValue;
+        int sumd = 0, dmax = 1;
+        for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+        const int h2 = (P.K - 1) / 2, TM = 256 - 2 * h2 * (sumd + P.n_dil);
+        gx = std::max(gx, (P.L + TM - 1) / TM);
+        const size_t rows = 256 + 2 * h2 * dmax + 5 * dmax;
+        lds = std::max(lds, rows * (P.Cp * 2 + 16));
+    }
+    for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    static const int mt_env = getenv("ZV_TRIPLE_MT") ? atoi(getenv("ZV_TRIPLE_MT")) : 2;      // A/B hook
+    if (mt_env == 1)
+        hipLaunchKernelGGL((resblock_triple_kernel<32, 1>), dim3(gx, 1, njobs), dim3(512), lds, s, js);
+    else if (mt_env == 4)
+        hipLaunchKernelGGL((resblock_triple_kernel<32, 4>), dim3(gx, 1, njobs), dim3(128), lds, s, js);
+    else
+        hipLaunchKernelGGL((resblock_triple_kernel<32, 2>), dim3(gx, 1, njobs), dim3(256), lds, s, js);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // vocoder tail: lrelu -> conv (C -> 1, K taps) + bias -> tanh.  Cout = 1 has no GEMM shape: each lane owns
 // one output sample and walks its K x C window in LDS (f16 operands, f32 accumulate).
 

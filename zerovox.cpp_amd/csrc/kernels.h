@@ -100,6 +100,30 @@ size_t     pair_weight_halfs(int Cp, int K);
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu);
 
+// ---- a whole HiFi-GAN residual block (reference src/hifigan.cpp:74-185: the loop over all dilations) in ONE launch:
+// a workgroup keeps a 256-row f32 tile of y in LDS, runs the n_dil fused pairs on it and writes the centre rows once.
+// HBM traffic per element: 4 B in (x halo factor) + 4 B out for the whole block instead of once per dilation pair.
+constexpr int TRIPLE_MAX_DIL = 3;
+struct TripleJob
+{
+    const float *y;                       // [L][Cp] f32 block input (may be shared by several jobs)
+    float       *out;                     // [L][Cp] f32 block output, must not alias y
+    const void  *w1[TRIPLE_MAX_DIL], *w2[TRIPLE_MAX_DIL];    // pack_pair_weight layout
+    const float *b1[TRIPLE_MAX_DIL], *b2[TRIPLE_MAX_DIL];
+    int          dil[TRIPLE_MAX_DIL];
+    int          n_dil;
+    int          L, Cp, K;
+    float        slope;
+    int          dbg;
+};
+struct TripleJobs
+{
+    TripleJob j[PAIR_MAX_JOBS];
+};
+// true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
+bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu);
+
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
 struct OutConvArgs
 {

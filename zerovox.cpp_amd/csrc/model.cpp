@@ -143,6 +143,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) fail(ZV_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
     n_cu = prop.multiProcessorCount;
     no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
+    no_triple_ = getenv("ZV_NO_TRIPLE") && atoi(getenv("ZV_NO_TRIPLE")) != 0;
     force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
@@ -736,7 +737,47 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
         group_begin();
-        for (int d = 0; d < voc_.n_dil; d++)
+        // narrow stages: the whole residual block (all dilations) of the three branches in ONE launch, y tile kept
+        // in LDS between the dilation pairs (launch_triple)
+        bool whole_block = fused && !no_triple_ && voc_.n_dil <= TRIPLE_MAX_DIL;
+        for (int jb = 0; jb < 3 && whole_block; jb++)
+        {
+            const ResPair &r0 = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil];
+            whole_block = triple_supported(Cp, r0.c1.K, voc_.dil, voc_.n_dil);
+            for (int d = 0; d < voc_.n_dil && whole_block; d++)
+                whole_block = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d].p1 != nullptr;
+        }
+        if (whole_block)
+        {
+            TripleJob tj[3];
+            double bb = 0, ff = 0;
+            for (int jb = 0; jb < 3; jb++)
+            {
+                TripleJob &t = tj[jb];
+                memset(&t, 0, sizeof(t));
+                t.y = ub;
+                t.out = y[jb];
+                t.n_dil = voc_.n_dil;
+                t.L = L;
+                t.Cp = Cp;
+                t.slope = 0.1f;
+                for (int d = 0; d < voc_.n_dil; d++)
+                {
+                    const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
+                    t.K = rp.c1.K;
+                    t.w1[d] = rp.p1;
+                    t.w2[d] = rp.p2;
+                    t.b1[d] = rp.c1.bias;
+                    t.b2[d] = rp.c2.bias;
+                    t.dil[d] = voc_.dil[d];
+                    bb += conv_bytes(L, C, C, rp.c1.K, false) + conv_bytes(L, C, C, rp.c2.K, true);
+                    ff += conv_flops(L, C, C, rp.c1.K) + conv_flops(L, C, C, rp.c2.K);
+                }
+                ycur[jb] = y[jb];
+            }
+            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu));
+        }
+        for (int d = 0; d < voc_.n_dil && !whole_block; d++)
         {
             ConvJob j1[3], j2[3];
             PairJob pj[3];
