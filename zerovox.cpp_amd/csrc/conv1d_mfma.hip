@@ -956,14 +956,14 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
 // kernel, hence the same bits.
 // LDS: X/XT region rows [0, R + 2*XM + slack), row XM + i <-> tile row i (XM = h2 * max(dil): zero margins, written
 // once).  The f32 tile itself stays in registers (see below).
-template <int CP, int MT>
-__global__ __launch_bounds__(64 * (8 / MT)) void resblock_triple_kernel(const TripleJobs jobs)
+template <int CP, int MT, int R>
+__global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(const TripleJobs jobs)
 {
     // 8 / MT waves, each owns 32*MT tile rows x all CP (= 32) channels; its slice of the f32 tile Y lives in 16*MT
     // registers per lane in the MFMA accumulator layout (row = (r&3) + 8*(r>>2) + 4*(lane>>5), channel = lane & 31)
     // for the whole kernel, so LDS only holds the f16 operand tile (26 KiB: several workgroups per CU).  Every wave
     // streams the same weight fragments (one output tile), MT row tiles per fragment.
-    constexpr int R = 256, NWV = 8 / MT, NTH = 64 * NWV;
+    constexpr int NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     static_assert(CP == 32, "one 32-channel output tile per wave");
     const TripleJob &P = jobs.j[blockIdx.z];
@@ -1100,10 +1100,16 @@ bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 
 hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu)
 {
-    (void)n_cu;
     if (njobs < 1 || njobs > PAIR_MAX_JOBS) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
+    static const int cfg_env = getenv("ZV_TRIPLE_CFG") ? atoi(getenv("ZV_TRIPLE_CFG")) : 0;      // A/B hook: MT*1000 + R
     TripleJobs js;
+    // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once the sequence is
+    // long enough for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
+    int Lmax = 0;
+    for (int i = 0; i < njobs; i++) Lmax = std::max(Lmax, jobs[i].L);
+    int R = (long)Lmax * njobs >= 7000L * n_cu ? 512 : 256, MT = 2;
+    if (cfg_env) { MT = cfg_env / 1000; R = cfg_env % 1000; }
     int gx = 1;
     size_t lds = 0;
     for (int i = 0; i < njobs; i++)
@@ -1114,21 +1120,19 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         if (P.Cp != jobs[0].Cp || !triple_supported(P.Cp, P.K, P.dil, P.n_dil)) return hipErrorInvalidValue;
         int sumd = 0, dmax = 1;
         for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
-        const int h2 = (P.K - 1) / 2, TM = 256 - 2 * h2 * (sumd + P.n_dil);
+        const int h2 = (P.K - 1) / 2, TM = R - 2 * h2 * (sumd + P.n_dil);
         gx = std::max(gx, (P.L + TM - 1) / TM);
-        const size_t rows = 256 + 2 * h2 * dmax + 5 * dmax;
+        const size_t rows = R + 2 * h2 * dmax + 5 * dmax;
         lds = std::max(lds, rows * (P.Cp * 2 + 16));
     }
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    static const int mt_env = getenv("ZV_TRIPLE_MT") ? atoi(getenv("ZV_TRIPLE_MT")) : 2;      // A/B hook
-    if (mt_env == 1)
-        hipLaunchKernelGGL((resblock_triple_kernel<32, 1>), dim3(gx, 1, njobs), dim3(512), lds, s, js);
-    else if (mt_env == 4)
-        hipLaunchKernelGGL((resblock_triple_kernel<32, 4>), dim3(gx, 1, njobs), dim3(128), lds, s, js);
-    else
-        hipLaunchKernelGGL((resblock_triple_kernel<32, 2>), dim3(gx, 1, njobs), dim3(256), lds, s, js);
-    return hipGetLastError();
+    const dim3 grid(gx, 1, njobs);
+#define ZV_TCASE(mt, r) \
+    if (MT == mt && R == r) { hipLaunchKernelGGL((resblock_triple_kernel<32, mt, r>), grid, dim3(64 * (r / 32 / mt)), lds, s, js); return hipGetLastError(); }
+    ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
+#undef ZV_TCASE
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------
