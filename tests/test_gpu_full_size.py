@@ -162,3 +162,25 @@ def test_vocoder_beyond_max_seq_len_and_regime_change(medium):
     print(f"T=2000 vs T=512 prefix: rms {err:.3e} (signal rms {_rms(short):.3f})")
     assert err <= 1e-4
     assert np.array_equal(long, model.vocode(mel))        # deterministic
+
+
+def test_repeatability_stress(medium):
+    """races show up as run-to-run differences: every stage is repeated 40 times at full size (all kernel families:
+    plain / split-K / fused pair / whole-block) and must return the same bits every time"""
+    from zerovox_cpp_amd import synth
+    model, g, tensors = medium
+    T = 512
+    mel = synth.vocoder_mel(g, tensors, 41, T)
+    hid = synth.decoder_hidden(g, 42, T)
+    ids, puncts, style = synth.encoder_inputs(g, 43, 96)
+    w0, m0 = model.vocode(mel), model.decode(hid, style)
+    e0 = model.encode(ids, puncts, style, T)
+    s0, nf0 = model.synthesize(ids, puncts, style, T)
+    for it in range(40):
+        assert np.array_equal(model.vocode(mel), w0), f"vocoder differs at repetition {it}"
+        assert np.array_equal(model.decode(hid, style), m0), f"decoder differs at repetition {it}"
+        if it % 4 == 0:
+            e = model.encode(ids, puncts, style, T)
+            assert np.array_equal(e["hidden"], e0["hidden"]) and e["n_frames"] == e0["n_frames"]
+            s, nf = model.synthesize(ids, puncts, style, T)
+            assert nf == nf0 and np.array_equal(s, s0)
