@@ -166,3 +166,29 @@ def test_loader_survives_corrupt_files_under_sanitizers():
     r = subprocess.run(["bash", os.path.join(root, "scripts", "asan_host.sh")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "no crash" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def _build_callsite(out_dir):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(out_dir), "facade_callsite")
+    pkg = os.path.join(root, "zerovox.cpp_amd")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-Wall", "-Werror", os.path.join(root, "tests", "native", "facade_callsite.cpp"),
+                        "-o", exe, "-L" + pkg, "-l:libzerovox_amd.so", "-Wl,-rpath," + pkg], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_reference_style_call_site_compiles(tmp_path):
+    """tests/native/facade_callsite.cpp constructs and drives the three stage classes with the argument lists of the
+    reference's own driver (src/zerovox.cpp:104-137, 326-334), using the ggml handle names: it must build against
+    csrc/zerovox.h without warnings and, with no GPU, fail with a message instead of aborting"""
+    import subprocess
+    import torch
+    from zerovox_cpp_amd import synth
+    exe = _build_callsite(tmp_path)
+    if not torch.cuda.is_available():
+        p = str(tmp_path / "t.gguf")
+        synth.write_checkpoint(p, synth.TINY, 5)
+        r = subprocess.run([exe, p, "8", str(tmp_path / "o.f32")], capture_output=True, text=True)
+        assert r.returncode == 1 and "facade_callsite:" in r.stderr

@@ -240,3 +240,30 @@ def test_decoder_edge_cases(models):
         err = float(np.max(np.abs(mel - ref)))
         print(f"decoder T={T} fill={fill}: max err {err:.3e}")
         assert err <= 2e-2
+
+
+def test_reference_style_call_site_runs(models, ckpt, tmp_path):
+    """the reference-style C++ caller (stage objects built like src/zerovox.cpp:104-137, eval chain :326-334) must
+    produce exactly what the C-ABI path produces for the same utterance"""
+    import subprocess
+    from test_boundary_cpu import _build_callsite
+    from zerovox_cpp_amd import synth
+    model, g, _ = models("small")
+    path, _, _ = ckpt("small")
+    exe = _build_callsite(tmp_path)
+    n = 24
+    out = tmp_path / "wav.f32"
+    r = subprocess.run([exe, path, str(n), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    i = np.arange(n, dtype=np.uint64)
+    ids = (1 + (i * 37 + 11) % 154).astype(np.int32)
+    puncts = (i % 3).astype(np.int32)
+    k = np.arange(g.E, dtype=np.uint64)
+    style = (np.float32(0.05) * (((k * np.uint64(2654435761)) % np.uint64(2 ** 32) % np.uint64(201)).astype(np.int64) - 100).astype(np.float32)
+             / np.float32(100.0)).astype(np.float32)
+    T = g.max_seq_len
+    e = model.encode(ids, puncts, style, T)
+    wav = model.vocode(model.decode(e["hidden"], style))
+    got = np.fromfile(out, np.float32)
+    assert got.shape == wav.shape and f"frames {e['n_frames']} " in r.stdout
+    assert np.array_equal(got, wav)
