@@ -331,6 +331,83 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 }
 
 
+// The same loop with the A fragments TWO steps ahead (four register sets in rotation) and a scheduling fence after
+// every step.  In the loop above hipcc moves each A read down next to the MFMA that consumes it (an lgkmcnt wait right
+// behind the read: LDS latency exposed on every step); a fence per step pins the reads where they are written, and two
+// steps (>= 4 MFMAs at MT = 2) cover the ds_read_b128 latency.  Used by the fused ResBlock kernels, which have the
+// registers to spare; in the generic kernel's widest instantiations the fences cost more registers than they gain.
+template <int CP, int MT, int NT, bool SWAP>
+__device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
+{
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;
+    constexpr bool HALF = NKC == 16;
+    const int nsb = (K * NKC + 3) >> 2;
+    const int nb = nsb >> 1;
+    half8 b0[4][NT], b1[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + u * 64];
+    wq += 4 * 64;
+    half8 a[4][MT];
+#define ZV_UN8(un) ((un) >= 8 ? (un) - 8 : 0)
+#define ZV_A_ADDR2(un) ((un) >= 8 ? tbn[(ZV_UN8(un) / NKC) % 4] + (ZV_UN8(un) % NKC) * 32 : tb[((un) / NKC) % 4] + ((un) % NKC) * 32)
+#define ZV_LOAD_A2(un)                                                                        \
+    {                                                                                         \
+        const char *np_ = ZV_A_ADDR2(un);                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 4][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+    }
+#define ZV_STEP2(u, bset) ZV_LOAD_A2((u) + 2) mfma_step<MT, NT, SWAP>(acc, a[(u) % 4], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
+    {
+        const char *tb[4], *tbn[4];
+        tb[0] = ap;
+#pragma unroll
+        for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
+#pragma unroll
+        for (int x = 0; x < 4; x++) tbn[x] = ap;
+        ZV_LOAD_A2(0) ZV_LOAD_A2(1)
+    }
+    for (int ib = 0; ib < nb; ib++)
+    {
+        const char *tb[4], *tbn[4];
+        tb[0] = ap;
+#pragma unroll
+        for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
+        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + TPB * dilRS;   // next body
+        tbn[0] = apn;
+#pragma unroll
+        for (int x = 1; x < 4; x++) tbn[x] = (x < TPB) ? apn + x * dilRS : apn;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b1[u][nt] = wq[nt * wseg + u * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        ZV_STEP2(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + (4 + u) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        ZV_STEP2(4, b1) ZV_STEP2(5, b1) ZV_STEP2(6, b1) ZV_STEP2(7, b1)
+        ap = apn;
+        wq += 8 * 64;
+    }
+    if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
+    {
+        const char *tb[4] = {ap, ap, ap, ap};
+        const char *tbn[4] = {ap, ap, ap, ap};
+        (void)tbn;
+        ZV_STEP2(0, b0) ZV_STEP2(1, b0)
+        mfma_step<MT, NT, SWAP>(acc, a[2], b0[2]);
+        mfma_step<MT, NT, SWAP>(acc, a[3], b0[3]);
+    }
+#undef ZV_STEP2
+#undef ZV_LOAD_A2
+#undef ZV_A_ADDR2
+#undef ZV_UN8
+}
+
 template <int MT, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
@@ -805,7 +882,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
             for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
-    if (!(P.dbg & 2)) mfma_taps<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K);
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
 
     // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
@@ -850,7 +927,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         for (int n = 0; n < NT; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
-    if (!(P.dbg & 2)) mfma_taps<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
     // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
@@ -1024,7 +1101,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2))
-            mfma_taps<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K);
+            mfma_taps_deep<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K);
         __syncthreads();                       // every wave is done reading X: the region becomes XT
         {
             const int hh = lane >> 5;
@@ -1060,7 +1137,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2))
-            mfma_taps<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K);
+            mfma_taps_deep<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K);
         {
             const float bias = P.b2[d][col];
 #pragma unroll
