@@ -115,6 +115,7 @@ class ZeroVOXModel
     uint32_t     get_num_frames() const { return n_frames; }
 
   private:
+    void release();
     zerovox_hparams  hparams;
     zv_model        *model;
     FS2Encoder      *encoder;

@@ -121,12 +121,14 @@ ZeroVOXModel::ZeroVOXModel(const std::string &fname)
     }
     catch (...)
     {
-        this->~ZeroVOXModel();
+        release();
         throw;
     }
 }
 
-ZeroVOXModel::~ZeroVOXModel()
+ZeroVOXModel::~ZeroVOXModel() { release(); }
+
+void ZeroVOXModel::release()
 {
     delete encoder;
     delete decoder;
