@@ -97,6 +97,17 @@ zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts,
 zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32_t T, float *mel);
 /* mel[T*num_mels] -> wav[T*hop_size] */
 zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav);
+
+/* ---- "next" row f-3 (streaming): chunked vocoding with halo ------------------------------------
+ * Vocodes mel[T][n_mels] in chunks of chunk_frames frames and hands every finished chunk to `sink` (called on the
+ * calling thread, in order, with a pointer that is valid only during the call).  Each chunk is computed from its own
+ * frames plus zv_vocoder_halo_frames() frames of context on either side, so the samples are bit-identical to those of
+ * zv_vocode() on the whole mel (every vocoder kernel sums in an order that does not depend on the tile or on T); the
+ * first audio is available after one chunk instead of after the whole utterance. */
+typedef void (*zv_wav_sink)(void *user, const float *wav, uint64_t first_sample, uint64_t n_samples);
+zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t chunk_frames, zv_wav_sink sink, void *user);
+/* frames of context (per side) outside which a mel frame cannot influence a sample: the vocoder's receptive field */
+uint32_t  zv_vocoder_halo_frames(zv_model *m);
 /* encoder -> decoder -> vocoder with every intermediate kept in HBM; wav[T*hop_size] */
 zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
                         uint32_t n, uint32_t T, float *wav, uint32_t *n_frames);

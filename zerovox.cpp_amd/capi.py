@@ -18,9 +18,12 @@ LIB_PATH = os.environ.get("ZEROVOX_AMD_LIB") or os.path.join(HERE, "libzerovox_a
 SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_device_alloc", "zv_device_free",
-    "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
+    "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
     "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect",
 ]
+
+
+WAV_SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.c_uint64)
 
 
 class HParams(C.Structure):
@@ -77,6 +80,9 @@ def load_library(path: Optional[str] = None):
     lib.zv_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.zv_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.zv_vocode_device.argtypes = [vp, vp, u32, vp]
+    lib.zv_vocode_stream.argtypes = [vp, fp, u32, u32, WAV_SINK, vp]
+    lib.zv_vocoder_halo_frames.argtypes = [vp]
+    lib.zv_vocoder_halo_frames.restype = u32
     lib.zv_decode_device.argtypes = [vp, vp, vp, u32, vp]
     lib.zv_synchronize.argtypes = [vp]
     lib.zv_set_graph_mode.argtypes = [vp, C.c_int]
@@ -131,6 +137,21 @@ class Model:
         wav = np.empty(T * self.hp.audio_hop_size, np.float32)
         self._chk(self.lib.zv_vocode(self.h, _ptr(mel), T, _ptr(wav)))
         return wav
+
+    def vocode_stream(self, mel: np.ndarray, chunk_frames: int):
+        """chunked vocoding with halo (zv_vocode_stream): list of (first_sample, samples) in delivery order"""
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        chunks = []
+
+        def sink(_user, wav, first, n):
+            chunks.append((int(first), np.ctypeslib.as_array(wav, shape=(int(n),)).copy()))
+
+        cb = WAV_SINK(sink)
+        self._chk(self.lib.zv_vocode_stream(self.h, _ptr(mel), mel.shape[0], chunk_frames, cb, None))
+        return chunks
+
+    def vocoder_halo_frames(self) -> int:
+        return int(self.lib.zv_vocoder_halo_frames(self.h))
 
     def decode(self, hidden: np.ndarray, style: np.ndarray) -> np.ndarray:
         hidden = np.ascontiguousarray(hidden, dtype=np.float32)

@@ -1,4 +1,5 @@
 // capi.cpp — the extern "C" boundary declared in include/zerovox_amd.h.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -167,6 +168,67 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
         M.vocode_dev_graph(d_mel, T, d_wav);
         ZV_HIP(hipMemcpyAsync(wav, d_wav, b_wav, hipMemcpyDeviceToHost, M.stream));
         M.sync();
+    });
+}
+
+uint32_t zv_vocoder_halo_frames(zv_model *m) { return m ? m->m->vocoder_halo_frames() : 0; }
+
+zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t chunk_frames, zv_wav_sink sink, void *user)
+{
+    return guarded([&] {
+        ZV_NEED(m && mel && sink, "null argument");
+        ZV_NEED(T > 0 && chunk_frames > 0, "T and chunk_frames must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        M.select_lane(0);
+        const size_t Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+        const uint32_t H = M.vocoder_halo_frames();
+        const uint32_t ctx_max = std::min<uint64_t>(T, (uint64_t)chunk_frames + 2 * H);
+        const size_t b_mel = ((size_t)T * Mm * 4 + 255) & ~(size_t)255, b_wav = (size_t)ctx_max * hop * 4;
+        M.reserve(1, ctx_max);
+        char *io = (char *)M.io_scratch(b_mel + b_wav);
+        float *d_mel = (float *)io, *d_wav = (float *)(io + b_mel);
+        // two pinned slots: chunk c is copied out and delivered while chunk c + 1 is being computed
+        const size_t slot = ((size_t)chunk_frames * hop * 4 + 255) & ~(size_t)255;
+        char *pin = (char *)M.pinned_scratch(2 * slot);
+        hipEvent_t done[2] = {nullptr, nullptr};
+        ZV_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
+        ZV_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
+        struct Pending { bool live; uint64_t first, n; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
+        auto deliver = [&](int k) {
+            if (!pend[k].live) return;
+            ZV_HIP(hipEventSynchronize(done[k]));
+            sink(user, (const float *)(pin + k * slot), pend[k].first, pend[k].n);
+            pend[k].live = false;
+        };
+        try
+        {
+            ZV_HIP(hipMemcpyAsync(d_mel, mel, (size_t)T * Mm * 4, hipMemcpyHostToDevice, M.stream));
+            int k = 0;
+            for (uint32_t a = 0; a < T; a += chunk_frames, k ^= 1)
+            {
+                const uint32_t b = std::min<uint64_t>(T, (uint64_t)a + chunk_frames);
+                const uint32_t c0 = a > H ? a - H : 0, c1 = std::min<uint64_t>(T, (uint64_t)b + H);
+                deliver(k);                                   // the slot we are about to overwrite
+                M.vocode_dev(d_mel + (size_t)c0 * Mm, c1 - c0, d_wav);
+                ZV_HIP(hipMemcpyAsync(pin + k * slot, d_wav + (size_t)(a - c0) * hop, (size_t)(b - a) * hop * 4, hipMemcpyDeviceToHost, M.stream));
+                ZV_HIP(hipEventRecord(done[k], M.stream));
+                pend[k] = {true, (uint64_t)a * hop, (uint64_t)(b - a) * hop};
+                deliver(k ^ 1);                               // the previous chunk, while this one runs
+            }
+            deliver(k);
+            deliver(k ^ 1);
+        }
+        catch (...)
+        {
+            hipStreamSynchronize(M.stream);
+            hipEventDestroy(done[0]);
+            hipEventDestroy(done[1]);
+            throw;
+        }
+        M.sync();
+        hipEventDestroy(done[0]);
+        hipEventDestroy(done[1]);
     });
 }
 

@@ -715,7 +715,9 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
         for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256;
         // measured (MI355X, medium geometry): the decoder's 512-row convs (144 plain workgroups) run 7 % faster per
         // chain on the split kernel, HiFi-GAN stage 1 (480 plain workgroups, three unequal jobs) does not
-        int smt = (ok && wgs(1) < (long)n_cu) ? 1 : 0;
+        // single-job launches only (decoder / encoder convs): the vocoder's three-branch launches stay on the plain
+        // kernel at every length, so that its output bits never depend on the sequence length (zv_vocode_stream)
+        int smt = (ok && njobs == 1 && wgs(1) < (long)n_cu) ? 1 : 0;
         if (e_sk >= 0 && ok) smt = e_sk;
         if (smt == 1 || smt == 2)
         {

@@ -443,6 +443,25 @@ Model::~Model()
 
 void Model::sync() { ZV_HIP(hipStreamSynchronize(stream)); }
 
+uint32_t Model::vocoder_halo_frames() const
+{
+    double frames = (voc_.in_conv.K - 1) / 2;            // input conv, at the frame rate
+    double rate = 1.0;                                   // samples per frame at the current stage
+    int sumd = 0;
+    for (int d = 0; d < voc_.n_dil; d++) sumd += voc_.dil[d];
+    for (int i = 0; i < voc_.n_up; i++)
+    {
+        // polyphase transposed conv: ups[i].K taps at the INPUT rate of the stage
+        frames += (double)voc_.ups[i].K / rate;
+        rate *= voc_.scales[i];
+        int kmax = 1;
+        for (int j = 0; j < voc_.n_rb; j++) kmax = std::max(kmax, voc_.pairs[((size_t)i * voc_.n_rb + j) * voc_.n_dil].c1.K);
+        frames += (double)((kmax - 1) / 2) * (sumd + voc_.n_dil) / rate;      // dilated conv + plain conv per dilation
+    }
+    frames += (double)((voc_.out_K - 1) / 2) / rate;
+    return (uint32_t)std::ceil(frames) + 1;
+}
+
 void Model::stash_lane()
 {
     if (lanes_.empty()) return;

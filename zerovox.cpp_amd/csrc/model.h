@@ -86,6 +86,9 @@ class Model
                            float *d_hidden);
 
     void reserve(uint32_t max_phonemes, uint32_t max_frames);
+    // receptive field of the vocoder in mel frames per side (input conv + per stage: transposed-conv taps and the widest
+    // residual block, converted from the stage's sample rate), rounded up, + 1
+    uint32_t vocoder_halo_frames() const;
     void sync();
 
     // Lanes: independent (stream, activation arena, I/O scratch) triples so that several utterances are in flight at
