@@ -81,8 +81,16 @@ class Oracle:
             if self.lib.zvo_set_tensor(self.ctx, name.encode(), _p(arr), dt, arr.ndim, ne) != 0:
                 raise RuntimeError(self.lib.zvo_last_error().decode())
         self.lib.zvo_set_order(self.ctx, order)
-        if threads:
-            self.lib.zvo_set_threads(self.ctx, threads)
+        # OpenMP's default is one thread per visible CPU; on a box whose CPU share is far below that (a GPU box shows
+        # every host core but grants ~16) hundreds of spinning threads turn a millisecond call into half a minute.
+        # Results do not depend on the thread count.
+        if not threads:
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            threads = max(1, min(16, avail))
+        self.lib.zvo_set_threads(self.ctx, threads)
 
     def __del__(self):
         try:

@@ -44,3 +44,29 @@ def test_vocoder_matches_oracle(models, geom, T):
     err = _rms(wav - ref)
     print(f"{geom} T={T}: wav rms err {err:.3e}, max {np.max(np.abs(wav - ref)):.3e}, signal rms {_rms(ref):.3f}")
     assert err <= WAV_RMS_GATE
+
+
+def test_vocoder_length_sweep(models):
+    """ragged lengths around every tile boundary of the kernels (32-row MFMA tiles, the fused kernels' 54..62-row and
+    136..232-row output tiles, single-tile and multi-tile sequences): each length against the oracle, and each as a
+    prefix of a longer utterance (bit-exact: the receptive field does not reach the cut)"""
+    from zerovox_cpp_amd import synth
+    from oracle import zvoracle
+    for geom, lengths in (("tiny", (2, 3, 5, 7, 9, 11, 13, 27, 28, 29, 47, 55, 63)), ("small", (2, 3, 7, 9, 10, 11, 19, 25, 33))):
+        model, g, tensors = models(geom)
+        orc = zvoracle.Oracle(tensors)
+        H = model.vocoder_halo_frames()
+        Tmax = max(lengths) + H + 8
+        mel = synth.vocoder_mel(g, tensors, 17, Tmax)
+        full = model.vocode(mel)
+        worst = 0.0
+        for T in lengths:
+            wav = model.vocode(mel[:T])
+            ref = orc.vocoder(mel[:T])
+            assert wav.shape == ref.shape and np.isfinite(wav).all()
+            worst = max(worst, _rms(wav - ref))
+            assert _rms(wav - ref) <= WAV_RMS_GATE, (geom, T)
+            # chunk [0, T) of the long utterance with halo == the first T frames of vocode(mel[:T + H])
+            ctx = model.vocode(mel[: T + H])
+            assert np.array_equal(ctx[: T * g.hop_size], full[: T * g.hop_size]), (geom, T)
+        print(f"{geom}: worst wav rms err over {len(lengths)} lengths {worst:.3e}")
