@@ -267,3 +267,38 @@ def test_reference_style_call_site_runs(models, ckpt, tmp_path):
     got = np.fromfile(out, np.float32)
     assert got.shape == wav.shape and f"frames {e['n_frames']} " in r.stdout
     assert np.array_equal(got, wav)
+
+
+def test_medium_geometry_length_sweep(models):
+    """decoder and encoder at the full-size channel counts (256-channel chunks, split-K kernel, 1 056-channel concat)
+    for lengths around the 32-row tile boundaries; gates as in the golden tests (the reference's own re-association
+    noise at this geometry is ~1e-3 rms / 4e-3 max on mel, 5e-4 on log-durations)"""
+    from zerovox_cpp_amd import synth
+    from oracle import zvoracle
+    model, g, tensors = models("medium")
+    orc = zvoracle.Oracle(tensors)
+    _, _, style = synth.encoder_inputs(g, 5, 4)
+    for T in (1, 2, 3, 31, 32, 33, 63, 65):
+        # distinct frames: InstanceNorm over a few (nearly) identical frames divides rounding noise by sqrt(eps) and
+        # says nothing about the kernels; the gate is relative to the oracle's own re-association noise for the case
+        hid = synth.decoder_hidden(g, 60 + T, T, frames_per_phoneme=1, fill=1.0)
+        mel = model.decode(hid, style)
+        orc.set_order(zvoracle.ORDER_GGML_AVX2)
+        ref = orc.decoder(hid, style)
+        orc.set_order(zvoracle.ORDER_SEQ_F32)
+        alt = orc.decoder(hid, style)
+        orc.set_order(zvoracle.ORDER_GGML_AVX2)
+        d, floor = mel - ref, alt - ref
+        print(f"decoder medium T={T}: rms {_rms(d):.3e} max {np.max(np.abs(d)):.3e} (floor rms {_rms(floor):.3e} max {np.max(np.abs(floor)):.3e})")
+        assert np.isfinite(mel).all(), T
+        assert _rms(d) <= max(3.0 * _rms(floor), 3e-3) and np.max(np.abs(d)) <= max(3.0 * np.max(np.abs(floor)), 2e-2), T
+    for N in (1, 2, 31, 33, 65):
+        ids, puncts, sty = synth.encoder_inputs(g, 70 + N, N)
+        T = 4 * N + 8
+        e = model.encode(ids, puncts, sty, T)
+        r = orc.encoder(g, ids, puncts, sty, T)
+        ld = float(np.max(np.abs(e["logdur"] - r["logdur"])))
+        print(f"encoder medium N={N}: logdur err {ld:.3e}, frames {e['n_frames']} vs {r['n_frames']}")
+        assert ld <= 5e-3, N
+        hid, nf = orc.length_regulator(e["features"], e["logdur"], T)
+        assert nf == e["n_frames"] and np.array_equal(hid, e["hidden"]), N
