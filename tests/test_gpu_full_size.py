@@ -220,3 +220,21 @@ def test_streaming_vocoder_is_bit_exact(medium, chunk):
     assert [c[0] for c in chunks] == [a * g.hop_size for a in range(0, T, chunk)]
     got = np.concatenate([c[1] for c in chunks])
     assert got.shape == full.shape and np.array_equal(got, full)
+
+
+def test_config4_batch_mixed_lengths_full_size(medium):
+    """configs[3]: mixed-length utterances (32..256 phonemes), T = 1 024 frames each, run as one batch on the in-flight
+    lanes; every utterance must equal its stand-alone run bit for bit (no batch padding leaks between utterances)"""
+    from zerovox_cpp_amd import sharding, synth
+    model, g, tensors = medium
+    lens = sharding.mixed_length_batch(3, 6)
+    assert min(lens) >= 32 and max(lens) <= 256
+    utts = []
+    for u, n in enumerate(lens):
+        ids, puncts, style = synth.encoder_inputs(g, 300 + u, n)
+        utts.append((ids, puncts, style, 1024))
+    got = model.synthesize_batch(utts)
+    for (ids, puncts, style, T), (wav, nf) in zip(utts, got):
+        ref, nf_ref = model.synthesize(ids, puncts, style, T)
+        assert nf == nf_ref and 0 < nf <= T and np.isfinite(wav).all()
+        assert np.array_equal(wav, ref)
