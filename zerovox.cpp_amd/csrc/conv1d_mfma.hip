@@ -712,12 +712,12 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
         const int e_sk = getenv("ZV_SPLITK") ? atoi(getenv("ZV_SPLITK")) : -1;      // 0 = off, else MT (1 | 2)
         const int e_lg = getenv("ZV_SPLITK_LG") ? atoi(getenv("ZV_SPLITK_LG")) : 0;       // coarser workgroup shapes (A/B)
         bool ok = ck == 256 && ntiles >= 4;
-        for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256;
+        for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256 && jobs[i].allow_splitk;
         // measured (MI355X, medium geometry): the decoder's 512-row convs (144 plain workgroups) run 7 % faster per
         // chain on the split kernel, HiFi-GAN stage 1 (480 plain workgroups, three unequal jobs) does not
-        // single-job launches only (decoder / encoder convs): the vocoder's three-branch launches stay on the plain
-        // kernel at every length, so that its output bits never depend on the sequence length (zv_vocode_stream)
-        int smt = (ok && njobs == 1 && wgs(1) < (long)n_cu) ? 1 : 0;
+        // only jobs that allow it (decoder / encoder convs): the vocoder stays on the plain kernel at every length, so
+        // that its output bits never depend on the sequence length (zv_vocode_stream)
+        int smt = (ok && wgs(1) < (long)n_cu) ? 1 : 0;
         if (e_sk >= 0 && ok) smt = e_sk;
         if (smt == 1 || smt == 2)
         {

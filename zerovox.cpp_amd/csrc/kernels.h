@@ -57,6 +57,9 @@ struct ConvJob
     int          ldo;
     int          dbg;            // timing-only ablation bits (ZV_DBG env): 1 no staging loads, 2 no MFMA, 4 no epilogue
     int          sk_lg_nw;       // split-K kernel: log2(output tiles per workgroup), filled in by launch_conv
+    int          allow_splitk;   // the caller accepts a sequence-length-dependent summation order (decoder / encoder
+                                 // convs: InstanceNorm / attention make those stages length-dependent anyway); the
+                                 // vocoder never sets it: its output bits must not depend on T (zv_vocode_stream)
 };
 
 constexpr int CONV_MAX_JOBS = 4;

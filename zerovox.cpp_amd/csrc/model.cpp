@@ -1007,6 +1007,7 @@ void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, 
         if (b.learned_sc)
         {
             ConvJob j = job(b.sc, L);
+            j.allow_splitk = 1;
             j.x0 = x;
             j.ldx = ldx;
             j.out = sc;
@@ -1016,6 +1017,7 @@ void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, 
         }
         {
             ConvJob j = job(b.conv1, L);
+            j.allow_splitk = 1;
             j.x0 = x;
             j.ldx = ldx;
             j.pro = PRO_NORM_ACT;
@@ -1030,6 +1032,7 @@ void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, 
         ZV_LAUNCH("dec_in_stats", 4.0 * L * Cm, 3.0 * L * Cm, launch_in_stats(stream, t1, b.conv1.Cout_p, L, Cm, 1e-5f, st2));
         {
             ConvJob j = job(b.conv2, L);
+            j.allow_splitk = 1;
             j.x0 = t1;
             j.ldx = b.conv1.Cout_p;
             j.pro = PRO_NORM_ACT;
@@ -1053,6 +1056,7 @@ void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, 
     // asr_res = IN_affine(conv1x1(enc_seq) + b) written straight into the concat buffer      (:382-404)
     {
         ConvJob j = job(dec_.asr0, L);
+        j.allow_splitk = 1;
         j.x0 = d_hidden;
         j.ldx = Ed;
         j.out = asr_t;
@@ -1077,6 +1081,7 @@ void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, 
     // to_out: conv1x1 E -> num_mels + b, emitted frame-major                                       (:432-441)
     {
         ConvJob j = job(dec_.to_out, L);
+        j.allow_splitk = 1;
         j.x0 = cur;
         j.ldx = ldc;
         j.out = d_mel;
@@ -1128,6 +1133,7 @@ Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_punc
                   launch_add_layernorm(stream, f, Ed, x, Ed, n, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed));
         {   // FFN: conv k9 + b -> relu (kept as f16 operand) -> conv k1 + b            (src/fs2encoder.cpp:190-214)
             ConvJob a = job(Ly.w1, n);
+            a.allow_splitk = 1;
             a.x0 = y;
             a.eact = 1;
             a.oslope = 0.f;
@@ -1135,6 +1141,7 @@ Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_punc
             a.out = hh;
             conv(&a, 1, "enc_conv", conv_bytes(n, Ed, Ly.w1.Cout, Ly.w1.K, false), conv_flops(n, Ed, Ly.w1.Cout, Ly.w1.K));
             ConvJob b = job(Ly.w2, n);
+            b.allow_splitk = 1;
             b.x0 = hh;
             b.pro = PRO_RAW_F16;
             b.out = f;
@@ -1148,6 +1155,7 @@ Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_punc
 
     auto predictor = [&](const VarPred &v, float *out) {        // VariancePredictor::graph (:386-440)
         ConvJob a = job(v.c1, n);
+        a.allow_splitk = 1;
         a.x0 = x;
         a.eact = 1;
         a.oslope = 0.f;
@@ -1156,6 +1164,7 @@ Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_punc
         ZV_LAUNCH("enc_layernorm", 8.0 * n * v.V, 8.0 * n * v.V,
                   launch_add_layernorm(stream, va, Vp, nullptr, 0, n, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp));
         ConvJob b = job(v.c2, n);
+        b.allow_splitk = 1;
         b.x0 = vb;
         b.pad = 1;                                              // literal 1 in the reference (:417)
         b.eact = 1;
