@@ -155,7 +155,8 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "conv1d_mfma_kernel (ResBlock Conv1d launches)",
+        roofline = {"bound": "hbm", "kernel": "HiFi-GAN ResBlock Conv1d launches (conv1d_mfma_kernel<1,4> x6, resblock_pair_kernel<128|64,2> x3 each, "
+                              "resblock_triple_kernel<32,2,256> x1 at 512 frames)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algo_bytes_per_launch": rb["algo_bytes"] / rb["launches"],
