@@ -562,7 +562,9 @@ void Model::arena_require(size_t bytes)
     arena_ = DeviceArena();
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) fail(ZV_ERR_OOM, "hipMalloc(%zu) for the activation arena failed", bytes);
-    ZV_HIP(hipMemset(p, 0, bytes));
+    // on the lane's own stream: the streams are non-blocking, so a memset on the null stream is NOT ordered with the
+    // kernels that follow on `stream` and could zero an arena they have already started to fill
+    ZV_HIP(hipMemsetAsync(p, 0, bytes, stream));
     arena_.base = (char *)p;
     arena_.cap = bytes;
 }
