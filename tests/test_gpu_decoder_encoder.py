@@ -6,6 +6,8 @@ here, per case, as the distance between two runs of the oracle that differ only 
 GPU must land within 1.5x of it.  Discrete decisions (durations, buckets) are compared with near-tie
 accounting: a flip is accepted only where the oracle's pre-rounding value sits within the noise band of a
 rounding boundary."""
+import os
+
 import numpy as np
 import pytest
 
@@ -302,3 +304,31 @@ def test_medium_geometry_length_sweep(models):
         assert ld <= 5e-3, N
         hid, nf = orc.length_regulator(e["features"], e["logdur"], T)
         assert nf == e["n_frames"] and np.array_equal(hid, e["hidden"]), N
+
+
+def test_nothing_depends_on_fresh_arena_contents(models, ckpt, tmp_path):
+    """ZV_ARENA_FILL=255 makes every new activation arena start as NaN patterns instead of zeros: the whole chain must
+    give the same bits as in this process (no kernel may read activation memory that it or a predecessor did not write)"""
+    import subprocess
+    import sys
+    from zerovox_cpp_amd import synth
+    model, g, _ = models("small")
+    path, _, _ = ckpt("small")
+    ids, puncts, style = synth.encoder_inputs(g, 77, 40)
+    wav, nf = model.synthesize(ids, puncts, style, 160)
+    out = tmp_path / "poison.npy"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from __graft_entry__ import load_package\nload_package()\n"
+        "from zerovox_cpp_amd import capi, synth\n"
+        f"m = capi.Model({path!r}, 0)\n"
+        "ids, puncts, style = synth.encoder_inputs(synth.SMALL, 77, 40)\n"
+        "b = m.synthesize_batch([(ids, puncts, style, 160)] * 5)\n"
+        "w, nf = m.synthesize(ids, puncts, style, 160)\n"
+        "assert all(np.array_equal(x[0], w) and x[1] == nf for x in b)\n"
+        f"np.save({str(out)!r}, w)\n")
+    env = dict(os.environ, ZV_ARENA_FILL="255")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out), wav)

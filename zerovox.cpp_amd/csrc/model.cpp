@@ -564,7 +564,9 @@ void Model::arena_require(size_t bytes)
     if (hipMalloc(&p, bytes) != hipSuccess) fail(ZV_ERR_OOM, "hipMalloc(%zu) for the activation arena failed", bytes);
     // on the lane's own stream: the streams are non-blocking, so a memset on the null stream is NOT ordered with the
     // kernels that follow on `stream` and could zero an arena they have already started to fill
-    ZV_HIP(hipMemsetAsync(p, 0, bytes, stream));
+    // ZV_ARENA_FILL=255 fills it with NaN patterns instead: no kernel may depend on what a fresh arena holds (test hook)
+    static const int fill = getenv("ZV_ARENA_FILL") ? atoi(getenv("ZV_ARENA_FILL")) : 0;
+    ZV_HIP(hipMemsetAsync(p, fill, bytes, stream));
     arena_.base = (char *)p;
     arena_.cap = bytes;
 }
