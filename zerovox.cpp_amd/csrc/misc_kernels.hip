@@ -274,6 +274,49 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     if (row >= n) return;
     const float *xr = x + (size_t)row * ldx;
     const float *rr = res ? res + (size_t)row * ldr : nullptr;
+    // rows of up to 64 * LN_MAXE channels are read once and kept in registers for the three passes (same per-lane
+    // summation order as the plain three-pass form below, so the same bits)
+    constexpr int LN_MAXE = 12;
+    if (C <= 64 * LN_MAXE)
+    {
+        float v[LN_MAXE];
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; e++)
+        {
+            const int c = lane + 64 * e;
+            v[e] = (c < C) ? (rr ? xr[c] + rr[c] : xr[c]) : 0.f;
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; e++)
+            if (lane + 64 * e < C) s += (double)v[e];
+        s = wave_sum(s);
+        const float mean = (float)(s / (double)C);
+        double s2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; e++)
+            if (lane + 64 * e < C)
+            {
+                const float d = v[e] - mean;
+                s2 += (double)(d * d);
+            }
+        s2 = wave_sum(s2);
+        const float var = (float)(s2 / (double)C);
+        const float scale = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; e++)
+        {
+            const int c = lane + 64 * e;
+            if (c < C)
+            {
+                float t = (v[e] - mean) * scale;
+                t = w[c] * t;
+                y[(size_t)row * ldy + c] = t + b[c];
+            }
+        }
+        for (int c = C + lane; c < Cp; c += 64) y[(size_t)row * ldy + c] = 0.f;
+        return;
+    }
     double s = 0.0;
     for (int c = lane; c < C; c += 64) s += (double)(rr ? xr[c] + rr[c] : xr[c]);
     s = wave_sum(s);
