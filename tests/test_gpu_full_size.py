@@ -238,3 +238,17 @@ def test_config4_batch_mixed_lengths_full_size(medium):
         ref, nf_ref = model.synthesize(ids, puncts, style, T)
         assert nf == nf_ref and 0 < nf <= T and np.isfinite(wav).all()
         assert np.array_equal(wav, ref)
+
+
+def test_maximum_sizes(medium):
+    """the largest shapes the checkpoint admits: as many phonemes as the position table has rows (max_seq_len + 1) and
+    T = max_seq_len frames, end to end; finite output, regulator saturates at T, deterministic"""
+    from zerovox_cpp_amd import synth
+    model, g, tensors = medium
+    N, T = g.max_seq_len + 1, g.max_seq_len
+    ids, puncts, style = synth.encoder_inputs(g, 91, N)
+    wav, nf = model.synthesize(ids, puncts, style, T)
+    assert wav.shape == (T * g.hop_size,) and np.isfinite(wav).all()
+    assert nf == T                                  # ~4 frames per phoneme: the frame budget is exhausted
+    wav2, nf2 = model.synthesize(ids, puncts, style, T)
+    assert nf2 == nf and np.array_equal(wav, wav2)
