@@ -336,7 +336,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 // behind the read: LDS latency exposed on every step); a fence per step pins the reads where they are written, and two
 // steps (>= 4 MFMAs at MT = 2) cover the ds_read_b128 latency.  Used by the fused ResBlock kernels, which have the
 // registers to spare; in the generic kernel's widest instantiations the fences cost more registers than they gain.
-template <int CP, int MT, int NT, bool SWAP>
+template <int CP, int MT, int NT, bool SWAP, int DEPTH = 2>
 __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
 {
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
@@ -350,15 +350,16 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + u * 64];
     wq += 4 * 64;
-    half8 a[4][MT];
+    static_assert(DEPTH >= 1 && DEPTH <= 7, "A fragments travel DEPTH steps ahead through a ring of 8 register sets");
+    half8 a[8][MT];
 #define ZV_UN8(un) ((un) >= 8 ? (un) - 8 : 0)
 #define ZV_A_ADDR2(un) ((un) >= 8 ? tbn[(ZV_UN8(un) / NKC) % 4] + (ZV_UN8(un) % NKC) * 32 : tb[((un) / NKC) % 4] + ((un) % NKC) * 32)
 #define ZV_LOAD_A2(un)                                                                        \
     {                                                                                         \
         const char *np_ = ZV_A_ADDR2(un);                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 4][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 8][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
     }
-#define ZV_STEP2(u, bset) ZV_LOAD_A2((u) + 2) mfma_step<MT, NT, SWAP>(acc, a[(u) % 4], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
+#define ZV_STEP2(u, bset) ZV_LOAD_A2((u) + DEPTH) mfma_step<MT, NT, SWAP>(acc, a[(u) % 8], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
     {
         const char *tb[4], *tbn[4];
         tb[0] = ap;
@@ -366,7 +367,13 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
         for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
 #pragma unroll
         for (int x = 0; x < 4; x++) tbn[x] = ap;
-        ZV_LOAD_A2(0) ZV_LOAD_A2(1)
+        ZV_LOAD_A2(0)
+        if constexpr (DEPTH > 1) ZV_LOAD_A2(1)
+        if constexpr (DEPTH > 2) ZV_LOAD_A2(2)
+        if constexpr (DEPTH > 3) ZV_LOAD_A2(3)
+        if constexpr (DEPTH > 4) ZV_LOAD_A2(4)
+        if constexpr (DEPTH > 5) ZV_LOAD_A2(5)
+        if constexpr (DEPTH > 6) ZV_LOAD_A2(6)
     }
     for (int ib = 0; ib < nb; ib++)
     {
@@ -398,9 +405,7 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
         const char *tb[4] = {ap, ap, ap, ap};
         const char *tbn[4] = {ap, ap, ap, ap};
         (void)tbn;
-        ZV_STEP2(0, b0) ZV_STEP2(1, b0)
-        mfma_step<MT, NT, SWAP>(acc, a[2], b0[2]);
-        mfma_step<MT, NT, SWAP>(acc, a[3], b0[3]);
+        ZV_STEP2(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)
     }
 #undef ZV_STEP2
 #undef ZV_LOAD_A2
