@@ -702,20 +702,12 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
     int MT = 4;
     while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
     while (MT > 1 && (size_t)(32 * MT * (4 / WN) + halo + dmax) * (ck * 2 + 16) > 80 * 1024) MT >>= 1;   // keep >= 2 workgroups per CU in LDS
-    {   // experiment hook: ZV_CONV_MT=<min MT> / ZV_CONV_WGS=<target workgroups per CU * 100>
+    {   // measurement hook (environment table): ZV_CONV_MT=<minimum MT>
         static const char *e_mt = getenv("ZV_CONV_MT");
-        static const char *e_w = getenv("ZV_CONV_WGS");
-        if (e_w)
-        {
-            const long tgt = atol(e_w) * n_cu / 100;
-            MT = 4;
-            while (MT > 1 && wgs(MT) < tgt) MT >>= 1;
-        }
         if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
     }
     {   // short sequences over 256-channel chunks: conv1d_splitk_kernel, workgroup shapes balanced per job
         const int e_sk = getenv("ZV_SPLITK") ? atoi(getenv("ZV_SPLITK")) : -1;      // 0 = off, else MT (1 | 2)
-        const int e_lg = getenv("ZV_SPLITK_LG") ? atoi(getenv("ZV_SPLITK_LG")) : 0;       // coarser workgroup shapes (A/B)
         bool ok = ck == 256 && ntiles >= 4;
         for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256 && jobs[i].allow_splitk;
         // measured (MI355X, medium geometry): the decoder's 512-row convs (144 plain workgroups) run 7 % faster per
@@ -738,8 +730,8 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
             for (int i = 0; i < njobs; i++)
             {
                 const double ratio = (double)cmax / ((double)jobs[i].K * jobs[i].Cin_p);
-                int l = lg_min + e_lg;
-                while (l < 3 && ratio >= 1.4142135623730951 * (double)(1 << (l - lg_min - e_lg))) l++;
+                int l = lg_min;
+                while (l < 3 && ratio >= 1.4142135623730951 * (double)(1 << (l - lg_min))) l++;
                 lg[i] = l > 3 ? 3 : l;
             }
             int ny = 1;
