@@ -81,4 +81,5 @@ if __name__ == "__main__":
     case("small", 64, 16, full=True)
     case("medium", 512, 64, full=False)      # BASELINE.json configs[0] (N=64) and [1] (vocoder, 512 frames)
     case("medium", 512, 128, full=False)     # configs[2]
+    case("medium", 1024, 256, full=False)    # configs[3]: T = 1 024, its longest utterance (256 phonemes)
     norm_kat()

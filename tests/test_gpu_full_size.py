@@ -26,11 +26,13 @@ def medium(ckpt):
     m.close()
 
 
-def test_config2_vocoder_512_frames_vs_reference_golden(medium):
-    """configs[1]: 80-ch mel, 512 frames -> 153600 samples; gate: wav RMS <= 1e-4 vs the reference's own output"""
+@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T1024_N256.npz"])
+def test_config2_vocoder_512_frames_vs_reference_golden(medium, fixture):
+    """configs[1]: 80-ch mel, 512 frames -> 153600 samples (and configs[3]'s T = 1 024); gate: wav RMS <= 1e-4 vs the
+    reference's own output"""
     from zerovox_cpp_amd import synth
     model, g, tensors = medium
-    z = np.load(os.path.join(GOLD, "medium_T512_N64.npz"))
+    z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
     wav = model.vocode(mel)
@@ -46,16 +48,17 @@ def test_config2_vocoder_512_frames_vs_reference_golden(medium):
     assert np.array_equal(wav, w2) and np.array_equal(w2, w3)
 
 
-def test_config2_decoder_512_frames_vs_reference_golden(medium):
+@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T1024_N256.npz"])
+def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
     from zerovox_cpp_amd import synth
     model, g, tensors = medium
-    z = np.load(os.path.join(GOLD, "medium_T512_N64.npz"))
+    z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     hid = synth.decoder_hidden(g, int(z["seed_hidden"]), T)
     _, _, style = synth.encoder_inputs(g, int(z["seed_enc"]), int(z["N"]))
     mel = model.decode(hid, style)
     d = mel.reshape(-1)[::s] - z["mel_samples"]
-    print(f"decoder T=512: mel err max {np.max(np.abs(d)):.3e} rms {_rms(d):.3e} (mel rms {float(z['mel_rms']):.3f}; "
+    print(f"decoder T={T}: mel err max {np.max(np.abs(d)):.3e} rms {_rms(d):.3e} (mel rms {float(z['mel_rms']):.3f}; "
           f"reference self-noise floor at this size: max ~3e-3..4e-3, rms ~1e-3 — SURVEY.md Appx D)")
     assert np.isfinite(mel).all()
     assert _rms(d) <= 2.0e-3 and np.max(np.abs(d)) <= 1.2e-2
@@ -66,12 +69,12 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium):
     finally:
         del os.environ["ZV_SPLITK"]
     d2 = mel_plain.reshape(-1)[::s] - z["mel_samples"]
-    print(f"decoder T=512, plain conv kernel: mel err max {np.max(np.abs(d2)):.3e} rms {_rms(d2):.3e}; "
+    print(f"decoder T={T}, plain conv kernel: mel err max {np.max(np.abs(d2)):.3e} rms {_rms(d2):.3e}; "
           f"split-K vs plain rms {_rms(mel - mel_plain):.3e}")
     assert _rms(d2) <= 2.0e-3 and np.max(np.abs(d2)) <= 1.2e-2
 
 
-@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz"])
+@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])
 def test_config1_3_encoder_vs_reference_golden(medium, fixture):
     """configs[0] (N=64) and configs[2] (N=128): integer decisions with near-tie accounting, pre-rounding taps close"""
     from zerovox_cpp_amd import synth
