@@ -70,3 +70,37 @@ def test_vocoder_length_sweep(models):
             ctx = model.vocode(mel[: T + H])
             assert np.array_equal(ctx[: T * g.hop_size], full[: T * g.hop_size]), (geom, T)
         print(f"{geom}: worst wav rms err over {len(lengths)} lengths {worst:.3e}")
+
+
+def test_gpu_vs_live_reference_fresh_seed(ckpt, tmp_path):
+    """no oracle, no committed fixture in between: the compiled reference itself (oracle/_ref/zvref, which travels to
+    the GPU box as a prebuilt binary) is run on a fresh seed and all three stages are compared with it directly"""
+    from zerovox_cpp_amd import capi, gguf, synth
+    from oracle import zvoracle
+    if not zvoracle.have_reference():
+        pytest.skip("oracle/_ref/zvref not built on this machine")
+    g = synth.SMALL
+    path = str(tmp_path / "fresh.gguf")
+    synth.write_checkpoint(path, g, 4321)
+    _, tensors = gguf.read_gguf(path)
+    model = capi.Model(path, 0)
+    T, N = 72, 18
+    mel = synth.vocoder_mel(g, tensors, 23, T)
+    r = zvoracle.run_reference(path, T=T, voc=mel)
+    wav = model.vocode(mel)
+    err = _rms(wav - r["wav"])
+    print(f"fresh seed, vocoder vs live reference: wav rms err {err:.3e} (signal rms {_rms(r['wav']):.3f})")
+    assert err <= WAV_RMS_GATE
+    ids, puncts, style = synth.encoder_inputs(g, 24, N)
+    hid = synth.decoder_hidden(g, 25, T)
+    r = zvoracle.run_reference(path, T=T, dec=(hid, style))
+    m = model.decode(hid, style)
+    d = m - r["mel"].reshape(m.shape)
+    print(f"fresh seed, decoder vs live reference: mel rms err {_rms(d):.3e} max {np.max(np.abs(d)):.3e}")
+    assert _rms(d) <= 3e-3 and np.max(np.abs(d)) <= 2e-2
+    r = zvoracle.run_reference(path, T=T, N=N, enc=(ids, puncts, style), E=g.E)
+    e = model.encode(ids, puncts, style, T)
+    ld = float(np.max(np.abs(e["logdur"] - r["logdur"])))
+    print(f"fresh seed, encoder vs live reference: logdur err {ld:.3e}, frames {e['n_frames']} vs {r['n_frames']}")
+    assert ld <= 5e-3 and abs(int(e["n_frames"]) - int(r["n_frames"])) <= 2
+    model.close()
