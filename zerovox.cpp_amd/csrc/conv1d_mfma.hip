@@ -795,6 +795,22 @@ void pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
             }
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: only the speed
+// depends on it) and each XCD has its own L2.  With grid.x a multiple of 8, workgroup b runs on XCD b % 8; giving XCD
+// x the x-th contiguous eighth of a job's time tiles keeps neighbouring tiles — which share their halo rows — behind the
+// same L2 instead of spreading every halo over two XCDs.
+__device__ __forceinline__ int zv_xcd_tile(int b, int ntiles)
+{
+#ifdef ZV_NO_XCD_MAP
+    return b;
+#else
+    // per job: its own tile count decides the eighths (jobs of one launch have different tile heights), so that
+    // every XCD gets an equal share of every job; workgroups beyond the job's tiles return a tile index >= ntiles
+    const int per = (ntiles + 7) >> 3, idx = b >> 3;
+    return idx < per ? (b & 7) * per + idx : ntiles;
+#endif
+}
+
 // leaky-ReLU for 0 <= slope <= 1 as max(x, x*slope): same bits as (x > 0 ? x : x*slope), one instruction less and
 // no compare/select pair; raw v_max_f32 keeps hipcc from adding a canonicalising multiply in front of fmaxf
 __device__ __forceinline__ float lrelu_max(float x, float s)
@@ -855,7 +871,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int L = P.L, K = P.K, dil = P.dil;
     const int h2 = (K - 1) / 2, h1 = h2 * dil;
     const int TM = BM - 2 * h2;
-    const int t0 = blockIdx.x * TM;
+    const int t0 = zv_xcd_tile(blockIdx.x, (L + TM - 1) / TM) * TM;
     if (t0 >= L) return;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -966,7 +982,7 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     const int TMmin = BM - (Kmax - 1);
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
-    dim3 grid((Lmax + TMmin - 1) / TMmin, 1, njobs);
+    dim3 grid(round_up((Lmax + TMmin - 1) / TMmin, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil
     const size_t lds = (size_t)(BM + (Kmax + 4) * dmax) * (CP * 2 + 16);
     auto kern = resblock_pair_kernel<CP, MT>;
@@ -1049,7 +1065,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
     for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
     const int H = h2 * (sumd + nd);
     const int TM = R - 2 * H;
-    const int t0 = blockIdx.x * TM;
+    const int t0 = zv_xcd_tile(blockIdx.x, (L + TM - 1) / TM) * TM;
     if (t0 >= L) return;
     const int XM = h2 * dmax;
     const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
@@ -1203,7 +1219,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     }
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid(gx, 1, njobs);
+    const dim3 grid(round_up(gx, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
 #define ZV_TCASE(mt, r) \
     if (MT == mt && R == r) { hipLaunchKernelGGL((resblock_triple_kernel<32, mt, r>), grid, dim3(64 * (r / 32 / mt)), lds, s, js); return hipGetLastError(); }
     ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
