@@ -126,3 +126,22 @@ def test_oracle_self_noise_floor(ckpt):
     b = orc.vocoder(mel)
     floor = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
     assert 0 < floor < 6e-5
+
+
+@pytest.mark.parametrize("k,dil,ic,oc,L", [(3, 1, 24, 40, 50), (7, 3, 32, 32, 97), (11, 5, 16, 48, 130), (1, 1, 33, 17, 20)])
+def test_oracle_conv_against_independent_torch_fp32(k, dil, ic, oc, L):
+    """an implementation that shares no code with the oracle: torch's fp32 conv1d on operands rounded to f16 exactly where
+    ggml rounds them (the im2col of the activations, the stored weights).  Products of two f16 values are exact in f32, so
+    the two differ only by f32 summation order: a few ulp of the accumulated magnitude"""
+    import torch
+    from oracle import zvoracle
+    rng = np.random.default_rng(k * 100 + dil)
+    x = rng.standard_normal((ic, L)).astype(np.float32)               # channels-first, like the reference's conv input
+    w = (rng.standard_normal((oc, ic, k)) / np.sqrt(ic * k)).astype(np.float16)
+    b = rng.standard_normal(oc).astype(np.float32)
+    pad = (k - 1) // 2 * dil
+    got = zvoracle.Oracle({}).conv1d(x, w, b, pad, dil)
+    x16 = torch.from_numpy(x.astype(np.float16).astype(np.float32))[None]
+    ref = torch.nn.functional.conv1d(x16, torch.from_numpy(w.astype(np.float32)), torch.from_numpy(b), padding=pad, dilation=dil)[0].numpy()
+    assert got.shape == ref.shape == (oc, L)
+    assert np.max(np.abs(got - ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))))
