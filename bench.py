@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's headline metric on MI355X: audio-seconds per wall-second (xRT).
+"""bench.py — the reference's headline metric on MI355X: audio-seconds per wall-second (xRT), end-to-end
+phoneme ids -> 22.05 kHz waveform.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): HiFi-GAN vocoder only, 80-ch mel, 512 frames, batch = 1 per GPU,
-medium geometry (512 -> 32 channels, hop 300), synthetic seeded weights and mel.  One step = one pass
-of the vocoder schedule over one utterance whose mel is already resident in HBM; the waveform stays in
-HBM.  value = (steps x 512 frames x 300 / 22050 s) x n_gpus / wall  — whole-job audio seconds per
-second.  Ranks share nothing on the data path (utterances are independent): weak scaling, no RCCL
-collective inside the timed region; torch.distributed only provides the barrier and the max-over-ranks.
+Workload (BASELINE.json configs[3]; with N = 8 it is configs[4]): per GPU a batch of 32 mixed-length utterances
+(32..256 phonemes, seeded), T = 1024 frames each, medium geometry (emb 512+16, 4 encoder layers, 512 -> 32 vocoder
+channels, hop 300), synthetic seeded weights.  One step = one zv_synthesize_batch call over the rank's utterances:
+HOST phoneme / punctuation ids and style vectors in, HOST waveforms out — the upload of the inputs, the three stages
+(FastSpeech2 encoder -> StyleTTS decoder -> HiFi-GAN, reference src/zerovox.cpp:326-334; all T frames are vocoded, as
+the reference does) and the download of the waveforms are all inside the timed region (SURVEY.md §8d "Wall").  The
+whole batch is one launch per kernel (segment tables in HBM) replayed as one hipGraph.
+
+value = steps x (audio seconds of all utterances of all ranks) / wall  — whole-job audio seconds per second.
+The global list has 32 x N utterances, rank r owns sharding.shard_utterances(32 N, N, r): weak scaling, no collective
+on the data path; torch.distributed only provides the barrier and the reductions of (audio, wall).
 
 Extra objects on the same JSON line:
-  roofline     — dominant kernel family (the ResBlock Conv1d launches): algorithmic bytes per launch
-                 (3.686 MB per mel frame for the 72 ResBlock convs + their weights) divided
-                 by the average launch duration measured live with HIP events on the model's stream
-                 (zv_profile_begin/_end: eager launches, one event pair per launch, same K steps).
-  cpu_baseline — the compiled reference (oracle/_ref/zvref, ggml CPU backend, x86-64-v3 build) timed on this
-                 host on the same 512-frame workload; falls back to our CPU port (oracle/zv_oracle.c).
+  roofline     — dominant kernel family (the HiFi-GAN ResBlock Conv1d launches) of the SAME batch workload:
+                 algorithmic bytes (3.686 MB per mel frame for the 72 ResBlock convs + their weights)
+                 divided by the launch time measured live with HIP events on the model's stream (zv_profile_begin/_end,
+                 eager launches, one event pair per stage's run of ResBlock launches).  `traffic` is NOT measured in
+                 this run: it is the PMC-derived HBM bytes per launch of the committed profile named in `traffic_source`.
+  cpu_baseline — the compiled reference (oracle/_ref/zvref: ggml CPU backend + the reference's own stage classes) timed
+                 end to end (encoder + decoder + vocoder back to back) on ONE utterance of the batch on this host's cores;
+                 falls back to our CPU port (oracle/zv_oracle.c) where the reference binary is absent.
+  extra        — BASELINE.json configs[1] (vocoder only, 512 frames, mel resident in HBM) and configs[2] (one 128-phoneme
+                 utterance end to end), the per-kernel-family table of the batch, PCIe-inclusive notes.
 """
 from __future__ import annotations
 
@@ -35,20 +45,24 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-FRAMES = 512
-SEED_W, SEED_MEL = 1234, 7
+MFMA_PEAK_TF = 2500.0          # dense f16 MFMA peak (same guide)
+UTTS_PER_GPU = 32
+FRAMES = 1024
+SEED_W, SEED_BATCH = 1234, 3
+TRAFFIC_PROFILE = "profiles/r02_resblock_traffic.json"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--utts-per-gpu", type=int, default=UTTS_PER_GPU)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--no-extras", action="store_true", help="skip the configs[2]/[3] extras (used under rocprofv3)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1]/[2] extras (used under rocprofv3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +79,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible — the HIP path has no CPU fallback")
     # rehearsal hook: ZV_BENCH_ONE_GPU=1 puts every rank on cuda:0 with the gloo backend, so the N > 1 code path
-    # (barrier, max-over-ranks, rank-0 JSON) can be exercised on a one-GPU box; never set by the driver
+    # (sharding, barrier, reductions, rank-0 JSON) can be exercised on a one-GPU box; never set by the driver
     one_gpu = os.environ.get("ZV_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
@@ -78,7 +92,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     load_package()
-    from zerovox_cpp_amd import capi, gguf, synth
+    from zerovox_cpp_amd import capi, gguf, sharding, synth
 
     g = synth.MEDIUM
     T = args.frames
@@ -89,16 +103,21 @@ def main():
         os.replace(ckpt + ".tmp", ckpt)
     if world > 1:
         dist.barrier()
-    _, tensors = gguf.read_gguf(ckpt)
-    mel = synth.vocoder_mel(g, tensors, SEED_MEL + rank, T)
+
+    # the global utterance list (32 per GPU) and this rank's contiguous shard of it
+    n_global = args.utts_per_gpu * world
+    lens = sharding.mixed_length_batch(SEED_BATCH, n_global)
+    lo, hi = sharding.shard_utterances(n_global, world, rank)
+    utts = []
+    for u in range(lo, hi):
+        ids, puncts, style = synth.encoder_inputs(g, 200 + u, lens[u])
+        utts.append((ids, puncts, style, T))
 
     model = capi.Model(ckpt, device=local_rank)
-    model.reserve(1, T)
     hop, sr = model.hp.audio_hop_size, model.hp.audio_sampling_rate
-    d_mel = model.device_alloc(mel.nbytes)
-    d_wav = model.device_alloc(T * hop * 4)
-    model.h2d(d_mel, mel)
     model.set_graph_mode(not args.no_graph)
+    call = model.prepare_batch(utts)            # host buffers allocated once; every run() is one zv_synthesize_batch
+    local_audio_per_step = sum(t * hop / sr for (_, _, _, t) in utts)
 
     def barrier():
         if world > 1:
@@ -107,166 +126,172 @@ def main():
         model.synchronize()
 
     for _ in range(args.warmup):
-        model.vocode_device(d_mel, T, d_wav)
+        call.run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.vocode_device(d_mel, T, d_wav)
+        call.run()
     barrier()
     dt = time.perf_counter() - t0
+    # whole-job rate: sum of audio over ranks / max of wall over ranks
+    value = sharding.aggregate_throughput(args.steps * local_audio_per_step, dt)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    wav = np.empty(T * hop, np.float32)
-    model.d2h(wav, d_wav)
-    if not np.isfinite(wav).all():
-        sys.exit("bench.py: non-finite waveform")
+    res = call.results()
+    if not all(np.isfinite(w).all() and 0 < nf <= T for (w, nf) in res):
+        sys.exit("bench.py: non-finite waveform or bad frame count")
 
-    audio_s = T * hop / sr
-    value = args.steps * audio_s * world / dt
-
-    # ---- roofline of the dominant kernel family: live HIP-event timing, eager launches, same K steps ----
-    roofline = None
-    kernels = []
+    # ---- roofline of the dominant kernel family, same batch workload: live HIP-event timing, eager launches ----
+    roofline, kernels = None, []
     if rank == 0:
         model.set_graph_mode(False)
-        for _ in range(3):
-            model.vocode_device(d_mel, T, d_wav)
-        model.synchronize()
+        call.run()
         model.profile_begin()
-        psteps = min(args.steps, 50)
+        psteps = 3
         for _ in range(psteps):
-            model.vocode_device(d_mel, T, d_wav)
+            call.run()
         stats = model.profile_end()
         tot_ms = sum(s["total_ms"] for s in stats)
         for s in stats:
             kernels.append({"name": s["name"], "launches_per_step": s["launches"] // psteps,
-                            "avg_us": 1e3 * s["total_ms"] / s["launches"], "share": s["total_ms"] / tot_ms,
-                            "algo_GBps": s["algo_bytes"] / (s["total_ms"] * 1e-3) / 1e9,
-                            "algo_TFLOPs": s["algo_flops"] / (s["total_ms"] * 1e-3) / 1e12})
+                            "avg_us": round(1e3 * s["total_ms"] / s["launches"], 2), "ms_per_step": round(s["total_ms"] / psteps, 4),
+                            "share": round(s["total_ms"] / tot_ms, 4),
+                            "algo_GBps": round(s["algo_bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1),
+                            "algo_TFLOPs": round(s["algo_flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)})
         rb = next(s for s in stats if s["name"] == "voc_resblock_conv")
         achieved = rb["algo_bytes"] / (rb["total_ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_resblock_traffic.json")
+        avg_us = 1e3 * rb["total_ms"] / rb["launches"]
+        traffic, traffic_src, traffic_gbps = None, None, None
+        tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = "static: %s (%s) — PMC passes of a committed profile, not measured in this run" % (
+                    TRAFFIC_PROFILE, tj.get("kernel_rev", "kernel rev unknown"))
+                if traffic and tj.get("avg_launch_us"):
+                    traffic_gbps = round(traffic / (tj["avg_launch_us"] * 1e-6) / 1e9, 1)
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "HiFi-GAN ResBlock Conv1d launches (conv1d_mfma_kernel<1,4> x6, resblock_pair_kernel<128|64,2> x3 each, "
-                              "resblock_triple_kernel<32,2,256> x1 at 512 frames)",
+        tf = rb["algo_flops"] / (rb["total_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "hbm",
+                    "kernel": "HiFi-GAN ResBlock Conv1d launches of the batch (resblock_pair_kernel<256|128|64,2> x3 each, "
+                              "resblock_triple_kernel<32,2,512> x1 per pass; every launch covers all utterances)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "frac_is": "ALGORITHMIC bytes of the unfused 72-conv formulation (SURVEY.md §8d) / launch time / 8 TB/s; "
+                               "the fused kernels move fewer real bytes (see traffic) and the wide stages are MFMA-bound",
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_GBps_in_that_profile": traffic_gbps,
                     "algo_bytes_per_launch": rb["algo_bytes"] / rb["launches"],
-                    "avg_launch_us": round(1e3 * rb["total_ms"] / rb["launches"], 2),
-                    "launches_per_step": rb["launches"] // psteps,
-                    "mfma_TFLOPs": round(rb["algo_flops"] / (rb["total_ms"] * 1e-3) / 1e12, 1),
+                    "avg_launch_us": round(avg_us, 2), "launches_per_step": rb["launches"] // psteps,
+                    "mfma_TFLOPs": round(tf, 1), "mfma_frac_of_dense_f16_peak": round(tf / MFMA_PEAK_TF, 4),
                     "timing": "hipEvent pair around each stage's run of consecutive ResBlock launches on the model's stream "
-                              "(eager, 3-6 launches per pair), %d steps" % psteps}
+                              "(eager), %d steps of the batch workload" % psteps}
 
-    # ---- PCIe-inclusive rate (host mel in, host wav out) — reported, never `value` ----
+    # ---- the other single-GPU configs of BASELINE.json, reported for reference (never `value`) ----
     extra = {}
     if rank == 0:
-        model.set_graph_mode(not args.no_graph)
-        for _ in range(3):
-            model.vocode(mel)
-        t1 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            model.vocode(mel)
-        extra["pcie_inclusive_xrt"] = round(reps * audio_s / (time.perf_counter() - t1), 1)
         extra["kernels"] = kernels
-        # the other single-GPU configs of BASELINE.json, reported for reference (never `value`):
-        #   configs[2] full chain phoneme -> wav, 128 phonemes, T = 512, batch 1 (host buffers in/out)
-        #   configs[3] batch of 32 mixed-length utterances (32..256 phonemes), T = 1024 each, 4 in-flight lanes
+        extra["timed_region_s"] = round(dt, 4)
         try:
             if args.no_extras:
                 raise RuntimeError("skipped (--no-extras)")
-            from zerovox_cpp_amd import sharding
-            model.set_graph_mode(False)
+            # configs[1]: HiFi-GAN vocoder only, 512 frames, batch 1, mel resident in HBM, hipGraph replay
+            _, tensors = gguf.read_gguf(ckpt)
+            T1 = 512
+            mel = synth.vocoder_mel(g, tensors, 7, T1)
+            d_mel = model.device_alloc(mel.nbytes)
+            d_wav = model.device_alloc(T1 * hop * 4)
+            model.h2d(d_mel, mel)
+            model.set_graph_mode(True)
+            for _ in range(5):
+                model.vocode_device(d_mel, T1, d_wav)
+            model.synchronize()
+            reps = 200
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                model.vocode_device(d_mel, T1, d_wav)
+            model.synchronize()
+            dt1 = (time.perf_counter() - t1) / reps
+            extra["configs1_vocoder_only_512f"] = {"xrt": round(T1 * hop / sr / dt1, 1), "ms": round(1e3 * dt1, 4),
+                                                   "note": "mel resident in HBM, wav left in HBM, hipGraph replay"}
+            for _ in range(3):
+                model.vocode(mel)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                model.vocode(mel)
+            extra["configs1_pcie_inclusive_xrt"] = round(20 * T1 * hop / sr / (time.perf_counter() - t1), 1)
+            model.device_free(d_mel)
+            model.device_free(d_wav)
+            # configs[2]: one 128-phoneme utterance end to end, T = 512, host buffers in / out
             ids, puncts, style = synth.encoder_inputs(g, 5, 128)
             for _ in range(3):
-                model.synthesize(ids, puncts, style, T)
+                model.synthesize(ids, puncts, style, T1)
             t1 = time.perf_counter()
-            for _ in range(10):
-                model.synthesize(ids, puncts, style, T)
-            extra["full_chain_128ph_T%d_xrt" % T] = round(10 * audio_s / (time.perf_counter() - t1), 1)
-            utts = []
-            for u, n in enumerate(sharding.mixed_length_batch(3, 32)):
-                i_, p_, s_ = synth.encoder_inputs(g, 200 + u, n)
-                utts.append((i_, p_, s_, 1024))
-            model.synthesize_batch(utts[:4])
+            for _ in range(20):
+                model.synthesize(ids, puncts, style, T1)
+            dt2 = (time.perf_counter() - t1) / 20
+            extra["configs2_full_chain_128ph_512f"] = {"xrt": round(T1 * hop / sr / dt2, 1), "ms": round(1e3 * dt2, 4)}
+            # the same 32 utterances one call each (what the batch path is measured against)
+            model.set_graph_mode(False)
             t1 = time.perf_counter()
-            model.synthesize_batch(utts)
-            extra["batch32_mixed_T1024_xrt"] = round(32 * 1024 * hop / sr / (time.perf_counter() - t1), 1)
-            # the same ResBlock kernels once a launch has many rounds of workgroups (8 192 frames in one call): the
-            # 512-frame single utterance of configs[1] is one round per launch and pays every launch's fixed
-            # latencies (dispatch, first loads, store drain) in full
-            TL = 8192
-            mel_l = np.tile(mel, (TL // T + 1, 1))[:TL]
-            d_ml, d_wl = model.device_alloc(mel_l.nbytes), model.device_alloc(TL * hop * 4)
-            model.h2d(d_ml, mel_l)
-            model.reserve(1, TL)
-            for _ in range(2):
-                model.vocode_device(d_ml, TL, d_wl)
-            model.synchronize()
-            model.profile_begin()
-            for _ in range(5):
-                model.vocode_device(d_ml, TL, d_wl)
-            st_l = model.profile_end()
-            rbl = next(s_ for s_ in st_l if s_["name"] == "voc_resblock_conv")
-            tot_l = sum(s_["total_ms"] for s_ in st_l) / 5
-            extra["long_utterance_T%d" % TL] = {
-                "resblock_algo_GBps": round(rbl["algo_bytes"] / (rbl["total_ms"] * 1e-3) / 1e9, 1),
-                "resblock_frac_of_hbm_peak": round(rbl["algo_bytes"] / (rbl["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "resblock_mfma_TFLOPs": round(rbl["algo_flops"] / (rbl["total_ms"] * 1e-3) / 1e12, 1),
-                "kernel_ms_per_pass": round(tot_l, 3), "xrt_kernel_time": round(TL * hop / sr / (tot_l * 1e-3), 1)}
-            model.device_free(d_ml)
-            model.device_free(d_wl)
+            for (i_, p_, s_, t_) in utts:
+                model.synthesize(i_, p_, s_, t_)
+            extra["one_by_one_xrt"] = round(local_audio_per_step / (time.perf_counter() - t1), 1)
         except Exception as e:      # these extras must never take the headline measurement down
             extra["extras_error"] = str(e)
 
-    # ---- CPU baseline on this host's cores (rank 0, N = 1 only) ----
+    # ---- CPU baseline on this host's cores (rank 0, N = 1 only): the compiled reference end to end on one utterance ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import zvoracle
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        ids0, pun0, sty0, T0 = utts[0]
+        audio0 = T0 * hop / sr
         if zvoracle.have_reference():
-            r = zvoracle.run_reference(ckpt, T=T, threads=threads, reps=3, voc=mel)
-            t_cpu = r["timing"]["voc_s"]
-            err = float(np.sqrt(np.mean((wav.astype(np.float64) - r["wav"]) ** 2)))
-            cpu = {"value": round(audio_s / t_cpu, 3), "unit": "x_realtime", "cores": threads, "kind": "reference",
-                   "sample": "compiled reference (ggml CPU, x86-64-v3 build), HiFi-GAN %d frames, best of 3 runs" % T,
-                   "seconds": round(t_cpu, 3), "gpu_vs_reference_wav_rms": err}
+            r = zvoracle.run_reference_chain(ckpt, ids0, pun0, sty0, T=T0, threads=threads)
+            t_cpu = r["timing"]["enc_s"] + r["timing"]["dec_s"] + r["timing"]["voc_s"]
+            err = float(np.sqrt(np.mean((res[0][0].astype(np.float64) - r["wav"]) ** 2)))
+            cpu = {"value": round(audio0 / t_cpu, 3), "unit": "x_realtime", "cores": threads, "kind": "reference",
+                   "sample": "compiled reference (ggml CPU backend, x86-64-v3 build), utterance 0 of the batch (%d phonemes, "
+                             "T = %d frames = %.2f s of audio), encoder + decoder + vocoder back to back, 1 run" % (len(ids0), T0, audio0),
+                   "seconds": round(t_cpu, 3), "stage_seconds": {k: round(r["timing"][k], 3) for k in ("enc_s", "dec_s", "voc_s")},
+                   "gpu_vs_reference_wav_rms_end_to_end": err, "n_frames": {"reference": r["n_frames"], "gpu": res[0][1]}}
         else:
+            _, tensors = gguf.read_gguf(ckpt)
             lib = zvoracle.build(native=True, out_dir=tmpdir)
             orc = zvoracle.Oracle(tensors, lib_path=lib, threads=threads)
-            Tc = min(T, 128)
+            Tc = 128
             t1 = time.perf_counter()
-            ref = orc.vocoder(mel[:Tc])
+            e = orc.encoder(g, ids0, pun0, sty0, Tc)
+            m_ = orc.decoder(e["hidden"], sty0)
+            orc.vocoder(m_)
             t_cpu = time.perf_counter() - t1
             cpu = {"value": round(Tc * hop / sr / t_cpu, 3), "unit": "x_realtime", "cores": threads, "kind": "port",
-                   "sample": "CPU port (oracle/zv_oracle.c, -march=native), HiFi-GAN first %d frames, 1 run" % Tc,
-                   "seconds": round(t_cpu, 3)}
+                   "sample": "CPU port (oracle/zv_oracle.c, -march=native), utterance 0 at T = %d frames, encoder + decoder + "
+                             "vocoder, 1 run" % Tc, "seconds": round(t_cpu, 3)}
 
     if rank == 0:
         out = {
-            "metric": "audio-seconds/wall-second (xRT), HiFi-GAN vocoding 80-ch mel -> 22.05 kHz wav",
+            "metric": "audio-seconds/wall-second (xRT) end-to-end phoneme->22.05 kHz wav",
             "value": round(value, 1), "unit": "x_realtime", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16*f16->f32 (MFMA), f32 activations", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: HiFi-GAN vocoder only, 80-ch mel, %d frames, batch=1 per GPU, "
-                                   "medium geometry (512ch, x300), mel resident in HBM, %s" %
-                                   (T, "eager launches" if args.no_graph else "hipGraph replay"),
-                       "frames": T, "audio_seconds_per_step": round(audio_s, 4), "utterances_per_gpu": 1,
-                       "parallelism": "independent utterances, one process per GPU, no collective"},
+            "vs_baseline": None, "dtype": "f16*f16->f32 (MFMA) convs, f32 (MFMA) attention/linear, f32 activations", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[3]%s: per GPU a batch of %d mixed-length utterances (32..256 phonemes), "
+                                   "T = %d frames each, full fs2encoder -> stylettsdec -> hifigan, host ids in / host wav out "
+                                   "(H2D + D2H inside the timed region), one launch per kernel for the whole batch, %s" %
+                                   (" x %d GPUs = configs[4]" % world if world > 1 else "", len(utts), T,
+                                    "eager launches" if args.no_graph else "hipGraph replay"),
+                       "utterances_per_gpu": len(utts), "utterances_total": n_global, "frames": T,
+                       "audio_seconds_per_step": round(local_audio_per_step * world, 3),
+                       "phonemes_rank0": int(sum(len(u[0]) for u in utts)),
+                       "parallelism": "independent utterances, contiguous shards, one process per GPU, no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))
-    model.device_free(d_mel)
-    model.device_free(d_wav)
     model.close()
     if world > 1:
         dist.destroy_process_group()

@@ -89,9 +89,12 @@ zv_status zv_model_reserve(zv_model *m, uint32_t max_phonemes, uint32_t max_fram
  * pitch_bucket[n], energy_bucket[n], features[n*E] — the pre-regulator values parity tests need. */
 zv_status zv_encode(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
                     uint32_t n, uint32_t T, float *hidden, uint32_t *n_frames);
+/* n = the encoder's max_n_phonemes: all n ids are embedded and attended to (no mask, src/fs2encoder.cpp:103-110,598-600);
+ * num_phonemes <= n = how many of them the length regulator walks (FS2Encoder::eval's argument, :622).  zv_encode is
+ * the num_phonemes == n case, which is what the reference's only caller passes (src/zerovox.cpp:200). */
 zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
-                         uint32_t n, uint32_t T, float *hidden, uint32_t *n_frames, float *features,
-                         float *logdur, float *pitch, float *energy, int32_t *pitch_bucket,
+                         uint32_t n, uint32_t num_phonemes, uint32_t T, float *hidden, uint32_t *n_frames,
+                         float *features, float *logdur, float *pitch, float *energy, int32_t *pitch_bucket,
                          int32_t *energy_bucket);
 /* hidden[T*E], style[E] -> mel[T*num_mels] frame-major */
 zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32_t T, float *mel);
@@ -112,13 +115,24 @@ uint32_t  zv_vocoder_halo_frames(zv_model *m);
 zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style,
                         uint32_t n, uint32_t T, float *wav, uint32_t *n_frames);
 
-/* n_utt independent utterances, each with its own (n_phonemes[u], T[u]) exactly as if zv_synthesize had been
- * called per utterance (no batch padding: padding would change the numbers, SURVEY Appx C-H2); utterances are
- * spread over up to 4 in-flight lanes (stream + arena each) so that the narrow stages of short utterances overlap.
- * BASELINE.json configs[3]/[4]; with several GPUs the caller shards the list (one model per GPU). */
+/* n_utt independent utterances, each with its own (n_phonemes[u], T[u]): bit for bit the result of n_utt zv_synthesize
+ * calls (no batch padding: padding would change the numbers, SURVEY Appx C-H2).  Up to 64 utterances / 64 Ki frames go
+ * through the three stages as ONE launch per kernel: tensors are row-concatenated over the group and a segment table in
+ * HBM tells every kernel where each utterance begins and ends, so the launches have many rounds of workgroups and the
+ * whole group — input upload included — is one hipGraph (captured once per capacity bucket when graph mode is on).
+ * BASELINE.json configs[3]/[4]; with several GPUs the caller shards the list (one model per GPU, no collective). */
 zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
                               const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T,
                               float *const *wav, uint32_t *n_frames);
+
+/* longest single utterance in frames (buffer descriptors address one utterance with 32-bit byte offsets; at most
+ * 32768 frames = 7.4 min of audio).  Longer T returns ZV_ERR_ARG; zv_vocode_stream has no such limit on the total. */
+uint32_t  zv_max_frames(const zv_model *m);
+
+/* the utterance the reference's ZeroVOXModel::eval() hard-codes (src/zerovox.cpp:204-314): 120 phoneme ids, 120
+ * punctuation ids, a 528-float style vector.  Pointers to static data; any argument may be NULL. */
+void      zv_demo_utterance(const int32_t **ids, const int32_t **puncts, const float **style, uint32_t *n_phonemes,
+                            uint32_t *style_len);
 
 /* ---- device-resident variants (inputs already in HBM; enqueue on the model's stream) ------- */
 void     *zv_device_alloc(zv_model *m, size_t bytes);

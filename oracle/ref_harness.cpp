@@ -18,6 +18,9 @@
 //         [--enc ids.i32 puncts.i32 style.f32 out_prefix]
 //         [--dec hidden.f32 style.f32 out_mel.f32]
 //         [--voc mel.f32 out_wav.f32]
+//         [--chain]   decoder input = the encoder's hidden, vocoder input = the decoder's mel (ZeroVOXModel::eval,
+//                     reference src/zerovox.cpp:326-334); the --dec / --voc input files are then ignored ("-" is fine)
+//         [--num n]   num_phonemes handed to FS2Encoder::eval (default N): the graph still encodes all N tokens
 // All files are raw little-endian arrays.  One JSON line with timings goes to stderr.
 
 #include <malloc.h>
@@ -88,7 +91,8 @@ int main(int argc, char **argv)
     const char *gguf_path = argv[1];
 
     int threads = 4, reps = 1;          // 4 = the reference's default (ggml.h GGML_DEFAULT_N_THREADS)
-    int N = -1, T = -1;
+    int N = -1, T = -1, num = -1;
+    bool chain = false;
     const char *enc_args[4] = {0}, *dec_args[3] = {0}, *voc_args[2] = {0};
     for (int i = 2; i < argc; i++)
     {
@@ -98,6 +102,8 @@ int main(int argc, char **argv)
         else if (a == "--reps")    { need(1); reps    = atoi(argv[++i]); }
         else if (a == "--N")       { need(1); N       = atoi(argv[++i]); }
         else if (a == "--T")       { need(1); T       = atoi(argv[++i]); }
+        else if (a == "--num")     { need(1); num     = atoi(argv[++i]); }
+        else if (a == "--chain")   { chain = true; }
         else if (a == "--enc")     { need(4); for (int j = 0; j < 4; j++) enc_args[j] = argv[++i]; }
         else if (a == "--dec")     { need(3); for (int j = 0; j < 3; j++) dec_args[j] = argv[++i]; }
         else if (a == "--voc")     { need(2); for (int j = 0; j < 2; j++) voc_args[j] = argv[++i]; }
@@ -184,6 +190,8 @@ int main(int argc, char **argv)
 
     double t_enc = 0, t_dec = 0, t_voc = 0;
     uint32_t n_frames = 0;
+    std::vector<float> chain_hidden, chain_mel;
+    if (num < 0) num = N;
 
     if (encoder)
     {
@@ -195,11 +203,12 @@ int main(int argc, char **argv)
         {
             double t0 = now_s();
             n_frames = encoder->eval((const int32_t *)ids.data(), (const int32_t *)pun.data(), (const float *)sty.data(),
-                                     (uint32_t)N, hidden.data());
+                                     (uint32_t)num, hidden.data());
             double dt = now_s() - t0;
             if (r == 0 || dt < t_enc) t_enc = dt;
         }
         std::string p = enc_args[3];
+        if (chain) chain_hidden = hidden;
         write_file(p + ".hidden.f32", hidden.data(), hidden.size() * 4);
         write_file(p + ".features.f32", ggml_get_data_f32(encoder->features), (size_t)N * E * 4);
         write_file(p + ".logdur.f32", ggml_get_data_f32(encoder->log_duration_prediction), (size_t)N * 4);
@@ -220,7 +229,12 @@ int main(int argc, char **argv)
 
     if (decoder)
     {
-        auto hid = read_file(dec_args[0]), sty = read_file(dec_args[1]);
+        auto sty = read_file(dec_args[1]);
+        std::vector<uint8_t> hid;
+        if (chain && !chain_hidden.empty())
+            hid.assign((const uint8_t *)chain_hidden.data(), (const uint8_t *)chain_hidden.data() + chain_hidden.size() * 4);
+        else
+            hid = read_file(dec_args[0]);
         if (hid.size() != (size_t)T * E * 4 || sty.size() != (size_t)E * 4)
         { fprintf(stderr, "zvref: decoder input sizes do not match T=%d E=%u\n", T, E); return 2; }
         std::vector<float> mel((size_t)T * hp.audio_num_mels);
@@ -231,12 +245,17 @@ int main(int argc, char **argv)
             double dt = now_s() - t0;
             if (r == 0 || dt < t_dec) t_dec = dt;
         }
+        if (chain) chain_mel = mel;
         write_file(dec_args[2], mel.data(), mel.size() * 4);
     }
 
     if (meldec)
     {
-        auto mel = read_file(voc_args[0]);
+        std::vector<uint8_t> mel;
+        if (chain && !chain_mel.empty())
+            mel.assign((const uint8_t *)chain_mel.data(), (const uint8_t *)chain_mel.data() + chain_mel.size() * 4);
+        else
+            mel = read_file(voc_args[0]);
         if (mel.size() != (size_t)T * hp.audio_num_mels * 4)
         { fprintf(stderr, "zvref: vocoder input size does not match T=%d\n", T); return 2; }
         std::vector<float> wav((size_t)T * hp.audio_hop_size);

@@ -176,14 +176,28 @@ def have_reference() -> bool:
     return os.path.exists(REF_BIN)
 
 
+def run_reference_chain(gguf_path: str, ids, puncts, style, *, T: int, threads: int = 4, num_phonemes: Optional[int] = None,
+                        num_mels: int = 80, hop: int = 300) -> dict:
+    """The three stage evals back to back on one utterance, as ZeroVOXModel::eval does (reference src/zerovox.cpp:326-334):
+    the decoder reads the encoder's hidden, the vocoder the decoder's mel.  Returns every stage's outputs + timings."""
+    return run_reference(gguf_path, N=len(ids), T=T, threads=threads, enc=(ids, puncts, style), dec=(None, style), voc=None,
+                         chain=True, num_phonemes=num_phonemes, num_mels=num_mels, hop=hop)
+
+
 def run_reference(gguf_path: str, *, N: Optional[int] = None, T: Optional[int] = None, threads: int = 4, reps: int = 1,
-                  enc=None, dec=None, voc=None, E: Optional[int] = None, num_mels: int = 80, hop: int = 300) -> dict:
-    """enc=(ids, puncts, style), dec=(hidden[T,E], style), voc=mel[T,80].  Returns outputs + timings."""
+                  enc=None, dec=None, voc=None, E: Optional[int] = None, num_mels: int = 80, hop: int = 300,
+                  chain: bool = False, num_phonemes: Optional[int] = None) -> dict:
+    """enc=(ids, puncts, style), dec=(hidden[T,E], style), voc=mel[T,80].  Returns outputs + timings.
+    chain=True: dec / voc inputs come from the previous stage (their input arrays may be None)."""
     if not have_reference():
         raise RuntimeError("oracle/_ref/zvref not built (run `make -C oracle ref` where /root/reference exists)")
     out = {}
     with tempfile.TemporaryDirectory() as td:
         cmd = [REF_BIN, gguf_path, "--threads", str(threads), "--reps", str(reps)]
+        if chain:
+            cmd += ["--chain"]
+        if num_phonemes is not None:
+            cmd += ["--num", str(num_phonemes)]
         if N is not None:
             cmd += ["--N", str(N)]
         if T is not None:
@@ -196,11 +210,13 @@ def run_reference(gguf_path: str, *, N: Optional[int] = None, T: Optional[int] =
             cmd += ["--enc", td + "/ids", td + "/puncts", td + "/style_e", td + "/enc"]
         if dec is not None:
             hidden, style = dec
-            np.asarray(hidden, np.float32).tofile(td + "/hidden")
+            if hidden is not None:
+                np.asarray(hidden, np.float32).tofile(td + "/hidden")
             np.asarray(style, np.float32).tofile(td + "/style_d")
             cmd += ["--dec", td + "/hidden", td + "/style_d", td + "/mel_out"]
-        if voc is not None:
-            np.asarray(voc, np.float32).tofile(td + "/mel_in")
+        if voc is not None or chain:
+            if voc is not None:
+                np.asarray(voc, np.float32).tofile(td + "/mel_in")
             cmd += ["--voc", td + "/mel_in", td + "/wav_out"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -219,6 +235,6 @@ def run_reference(gguf_path: str, *, N: Optional[int] = None, T: Optional[int] =
             out["n_frames"] = int(np.fromfile(td + "/enc.nframes.i32", np.int32)[0])
         if dec is not None:
             out["mel"] = np.fromfile(td + "/mel_out", np.float32).reshape(-1, num_mels)
-        if voc is not None:
+        if voc is not None or chain:
             out["wav"] = np.fromfile(td + "/wav_out", np.float32)
     return out

@@ -62,16 +62,8 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
           f"reference self-noise floor at this size: max ~3e-3..4e-3, rms ~1e-3 — SURVEY.md Appx D)")
     assert np.isfinite(mel).all()
     assert _rms(d) <= 2.0e-3 and np.max(np.abs(d)) <= 1.2e-2
-    # T = 512 runs the decoder's convs on the split-K kernel; longer utterances take the plain kernel: same gates
-    os.environ["ZV_SPLITK"] = "0"
-    try:
-        mel_plain = model.decode(hid, style)
-    finally:
-        del os.environ["ZV_SPLITK"]
-    d2 = mel_plain.reshape(-1)[::s] - z["mel_samples"]
-    print(f"decoder T={T}, plain conv kernel: mel err max {np.max(np.abs(d2)):.3e} rms {_rms(d2):.3e}; "
-          f"split-K vs plain rms {_rms(mel - mel_plain):.3e}")
-    assert _rms(d2) <= 2.0e-3 and np.max(np.abs(d2)) <= 1.2e-2
+    # the decoder has one kernel regime at every length: a second run gives the same bits
+    assert np.array_equal(model.decode(hid, style), mel)
 
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])
@@ -226,21 +218,26 @@ def test_streaming_vocoder_is_bit_exact(medium, chunk):
 
 
 def test_config4_batch_mixed_lengths_full_size(medium):
-    """configs[3]: mixed-length utterances (32..256 phonemes), T = 1 024 frames each, run as one batch on the in-flight
-    lanes; every utterance must equal its stand-alone run bit for bit (no batch padding leaks between utterances)"""
+    """configs[3]: 32 mixed-length utterances (32..256 phonemes), T = 1 024 frames each, as ONE launch per kernel
+    (segment tables in HBM); every utterance must equal its stand-alone run bit for bit (no batch padding, nothing
+    leaks between neighbouring utterances of the concatenated buffers), eager and as a replayed hipGraph"""
     from zerovox_cpp_amd import sharding, synth
     model, g, tensors = medium
-    lens = sharding.mixed_length_batch(3, 6)
+    lens = sharding.mixed_length_batch(3, 32)
     assert min(lens) >= 32 and max(lens) <= 256
     utts = []
     for u, n in enumerate(lens):
         ids, puncts, style = synth.encoder_inputs(g, 300 + u, n)
         utts.append((ids, puncts, style, 1024))
     got = model.synthesize_batch(utts)
-    for (ids, puncts, style, T), (wav, nf) in zip(utts, got):
+    model.set_graph_mode(True)
+    got_g = model.synthesize_batch(utts)          # capture
+    got_g = model.synthesize_batch(utts)          # replay
+    model.set_graph_mode(False)
+    for (ids, puncts, style, T), (wav, nf), (wav_g, nf_g) in zip(utts, got, got_g):
         ref, nf_ref = model.synthesize(ids, puncts, style, T)
-        assert nf == nf_ref and 0 < nf <= T and np.isfinite(wav).all()
-        assert np.array_equal(wav, ref)
+        assert nf == nf_ref == nf_g and 0 < nf <= T and np.isfinite(wav).all()
+        assert np.array_equal(wav, ref) and np.array_equal(wav_g, ref)
 
 
 def test_maximum_sizes(medium):

@@ -19,7 +19,7 @@ SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
-    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect",
+    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance",
 ]
 
 
@@ -67,7 +67,11 @@ def load_library(path: Optional[str] = None):
     lib.zv_model_get_hparams.argtypes = [vp, C.POINTER(HParams)]
     lib.zv_model_reserve.argtypes = [vp, u32, u32]
     lib.zv_encode.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
-    lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
+    lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
+    lib.zv_max_frames.argtypes = [vp]
+    lib.zv_max_frames.restype = u32
+    lib.zv_demo_utterance.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+    lib.zv_demo_utterance.restype = None
     lib.zv_decode.argtypes = [vp, fp, fp, u32, fp]
     lib.zv_vocode.argtypes = [vp, fp, u32, fp]
     lib.zv_synthesize.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
@@ -161,7 +165,11 @@ class Model:
         self._chk(self.lib.zv_decode(self.h, _ptr(hidden), _ptr(style), T, _ptr(mel)))
         return mel
 
-    def encode(self, ids, puncts, style, T: int) -> dict:
+    def max_frames(self) -> int:
+        return int(self.lib.zv_max_frames(self.h))
+
+    def encode(self, ids, puncts, style, T: int, num_phonemes: Optional[int] = None) -> dict:
+        """num_phonemes < len(ids): all ids are encoded, the length regulator walks the first num_phonemes (FS2Encoder::eval)"""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         puncts = np.ascontiguousarray(puncts, dtype=np.int32)
         style = np.ascontiguousarray(style, dtype=np.float32)
@@ -170,7 +178,8 @@ class Model:
                    logdur=np.empty(N, np.float32), pitch=np.empty(N, np.float32), energy=np.empty(N, np.float32),
                    pitch_bucket=np.empty(N, np.int32), energy_bucket=np.empty(N, np.int32))
         nf = C.c_uint32(0)
-        self._chk(self.lib.zv_encode_taps(self.h, _ptr(ids), _ptr(puncts), _ptr(style), N, T, _ptr(out["hidden"]),
+        self._chk(self.lib.zv_encode_taps(self.h, _ptr(ids), _ptr(puncts), _ptr(style), N,
+                                          N if num_phonemes is None else num_phonemes, T, _ptr(out["hidden"]),
                                           C.byref(nf), _ptr(out["features"]), _ptr(out["logdur"]), _ptr(out["pitch"]),
                                           _ptr(out["energy"]), _ptr(out["pitch_bucket"]), _ptr(out["energy_bucket"])))
         out["n_frames"] = int(nf.value)
@@ -185,24 +194,16 @@ class Model:
         self._chk(self.lib.zv_synthesize(self.h, _ptr(ids), _ptr(puncts), _ptr(style), len(ids), T, _ptr(wav), C.byref(nf)))
         return wav, int(nf.value)
 
+    def prepare_batch(self, utterances) -> "BatchCall":
+        """argument arrays and output buffers of one zv_synthesize_batch call, built once (a C host would keep its
+        buffers too): .run() is exactly one call of the C entry point, .results() the (wav, n_frames) list"""
+        return BatchCall(self, utterances)
+
     def synthesize_batch(self, utterances):
         """utterances: list of (ids, puncts, style, T) -> list of (wav, n_frames); each utterance keeps its own (N, T)"""
-        n = len(utterances)
-        keep, wavs = [], []
-        P = C.c_void_p * n
-        ids_p, pun_p, sty_p, wav_p = P(), P(), P(), P()
-        Ns, Ts, nf = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_uint32 * n)()
-        for i, (ids, puncts, style, T) in enumerate(utterances):
-            a = np.ascontiguousarray(ids, dtype=np.int32)
-            b = np.ascontiguousarray(puncts, dtype=np.int32)
-            c = np.ascontiguousarray(style, dtype=np.float32)
-            w = np.empty(T * self.hp.audio_hop_size, np.float32)
-            keep += [a, b, c]
-            wavs.append(w)
-            ids_p[i], pun_p[i], sty_p[i], wav_p[i] = a.ctypes.data, b.ctypes.data, c.ctypes.data, w.ctypes.data
-            Ns[i], Ts[i] = len(a), T
-        self._chk(self.lib.zv_synthesize_batch(self.h, n, ids_p, pun_p, sty_p, Ns, Ts, wav_p, nf))
-        return [(wavs[i], int(nf[i])) for i in range(n)]
+        call = BatchCall(self, utterances)
+        call.run()
+        return call.results()
 
     # ---- device-resident API ----
     def device_alloc(self, nbytes: int) -> int:
@@ -246,6 +247,44 @@ class Model:
         self._chk(self.lib.zv_profile_end(self.h, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
                      algo_bytes=arr[i].algo_bytes, algo_flops=arr[i].algo_flops) for i in range(min(cap, n.value))]
+
+
+class BatchCall:
+    def __init__(self, model: Model, utterances):
+        self.model = model
+        n = self.n = len(utterances)
+        self.keep, self.wavs = [], []
+        P = C.c_void_p * n
+        self.ids_p, self.pun_p, self.sty_p, self.wav_p = P(), P(), P(), P()
+        self.Ns, self.Ts, self.nf = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_uint32 * n)()
+        for i, (ids, puncts, style, T) in enumerate(utterances):
+            a = np.ascontiguousarray(ids, dtype=np.int32)
+            b = np.ascontiguousarray(puncts, dtype=np.int32)
+            c = np.ascontiguousarray(style, dtype=np.float32)
+            w = np.zeros(T * model.hp.audio_hop_size, np.float32)
+            self.keep += [a, b, c]
+            self.wavs.append(w)
+            self.ids_p[i], self.pun_p[i], self.sty_p[i], self.wav_p[i] = a.ctypes.data, b.ctypes.data, c.ctypes.data, w.ctypes.data
+            self.Ns[i], self.Ts[i] = len(a), T
+
+    def run(self):
+        m = self.model
+        m._chk(m.lib.zv_synthesize_batch(m.h, self.n, self.ids_p, self.pun_p, self.sty_p, self.Ns, self.Ts, self.wav_p, self.nf))
+
+    def results(self):
+        return [(self.wavs[i], int(self.nf[i])) for i in range(self.n)]
+
+
+def demo_utterance():
+    """(ids[120], puncts[120], style[528]) of the reference's ZeroVOXModel::eval() (needs no GPU)"""
+    lib = load_library()
+    a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n, ns = C.c_uint32(0), C.c_uint32(0)
+    lib.zv_demo_utterance(C.byref(a), C.byref(b), C.byref(c), C.byref(n), C.byref(ns))
+    ids = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_int32)), shape=(n.value,)).copy()
+    pun = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_int32)), shape=(n.value,)).copy()
+    sty = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_float)), shape=(ns.value,)).copy()
+    return ids, pun, sty
 
 
 def gguf_inspect(path: str, tensor_index: int = -1):

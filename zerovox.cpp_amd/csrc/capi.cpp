@@ -3,6 +3,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 #include "model.h"
@@ -86,38 +88,65 @@ zv_status zv_model_reserve(zv_model *m, uint32_t max_phonemes, uint32_t max_fram
 
 static void check_ids(const Model &M, const int32_t *ids, const int32_t *puncts, uint32_t n)
 {
-    // the reference aborts inside ggml_get_rows on a bad id (ggml-cpu.c:8456); 155 / 7 rows (src/zerovox.h:35-36)
+    // the reference aborts inside ggml_get_rows on a bad id (ggml-cpu.c:8456); the tables have 155 / 7 rows in the
+    // reference's checkpoints (src/zerovox.h:35-36) — the limit is what the loaded file holds
+    const int wmax = M.wemb_rows() - 1, pmax = M.pemb_rows() - 1;
     for (uint32_t i = 0; i < n; i++)
     {
-        if (ids[i] < 0 || ids[i] > 154) zv::fail(ZV_ERR_ARG, "phoneme id %d at position %u is outside [0, 154]", ids[i], i);
-        if (puncts[i] < 0 || puncts[i] > 6) zv::fail(ZV_ERR_ARG, "punctuation id %d at position %u is outside [0, 6]", puncts[i], i);
+        if (ids[i] < 0 || ids[i] > wmax) zv::fail(ZV_ERR_ARG, "phoneme id %d at position %u is outside [0, %d]", ids[i], i, wmax);
+        if (puncts[i] < 0 || puncts[i] > pmax) zv::fail(ZV_ERR_ARG, "punctuation id %d at position %u is outside [0, %d]", puncts[i], i, pmax);
     }
-    (void)M;
 }
 
-zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
-                         float *hidden, uint32_t *n_frames, float *features, float *logdur, float *pitch, float *energy,
-                         int32_t *pitch_bucket, int32_t *energy_bucket)
+#include "demo_utterance.inc"
+
+void zv_demo_utterance(const int32_t **ids, const int32_t **puncts, const float **style, uint32_t *n_phonemes, uint32_t *style_len)
+{
+    if (ids) *ids = kDemoIds;
+    if (puncts) *puncts = kDemoPuncts;
+    if (style) *style = kDemoStyle;
+    if (n_phonemes) *n_phonemes = 120;
+    if (style_len) *style_len = 528;
+}
+
+uint32_t zv_max_frames(const zv_model *m) { return m ? m->m->max_frames_per_utterance() : 0; }
+
+static void check_T(const Model &M, uint32_t T)
+{
+    if (T == 0) zv::fail(ZV_ERR_ARG, "T must be > 0");
+    if (T > M.max_frames_per_utterance())
+        zv::fail(ZV_ERR_ARG, "T = %u exceeds zv_max_frames() = %u frames per utterance (32-bit offsets inside a segment); use zv_vocode_stream for longer audio",
+                 T, M.max_frames_per_utterance());
+}
+
+zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n,
+                         uint32_t num_phonemes, uint32_t T, float *hidden, uint32_t *n_frames, float *features, float *logdur,
+                         float *pitch, float *energy, int32_t *pitch_bucket, int32_t *energy_bucket)
 {
     return guarded([&] {
         ZV_NEED(m && ids && puncts && style && hidden, "null argument");
-        ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
+        ZV_NEED(n > 0, "n must be > 0");
+        ZV_NEED(num_phonemes <= n, "num_phonemes exceeds n");
         Model &M = *m->m;
+        check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         check_ids(M, ids, puncts, n);
         const size_t E = M.E();
         const size_t b_ids = (size_t)n * 4, b_sty = E * 4, b_hid = (size_t)T * E * 4;
-        char *io = (char *)M.io_scratch(2 * b_ids + b_sty + b_hid + 1024);
+        char *io = (char *)M.io_scratch(256 + 2 * b_ids + b_sty + b_hid + 1024);
+        int32_t *d_nf = (int32_t *)io;
+        io += 256;
         int32_t *d_ids = (int32_t *)io, *d_pun = (int32_t *)(io + b_ids);
         float *d_sty = (float *)(io + 2 * b_ids + 256 - (2 * b_ids) % 256);
         float *d_hid = (float *)((char *)d_sty + ((b_sty + 255) & ~(size_t)255));
         ZV_HIP(hipMemcpyAsync(d_ids, ids, b_ids, hipMemcpyHostToDevice, M.stream));
         ZV_HIP(hipMemcpyAsync(d_pun, puncts, b_ids, hipMemcpyHostToDevice, M.stream));
         ZV_HIP(hipMemcpyAsync(d_sty, style, b_sty, hipMemcpyHostToDevice, M.stream));
-        Model::EncoderTaps t = M.encode_dev(d_ids, d_pun, d_sty, n, T, d_hid);
+        const zv::Batch bt = zv::Batch::single(n, T, num_phonemes);
+        Model::EncoderTaps t = M.encode_dev(bt, d_ids, d_pun, d_sty, d_hid, d_nf);
         ZV_HIP(hipMemcpyAsync(hidden, d_hid, b_hid, hipMemcpyDeviceToHost, M.stream));
         int32_t nf = 0;
-        ZV_HIP(hipMemcpyAsync(&nf, t.n_frames, 4, hipMemcpyDeviceToHost, M.stream));
+        ZV_HIP(hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, M.stream));
         if (features) ZV_HIP(hipMemcpyAsync(features, t.features, (size_t)n * E * 4, hipMemcpyDeviceToHost, M.stream));
         if (logdur) ZV_HIP(hipMemcpyAsync(logdur, t.logdur, b_ids, hipMemcpyDeviceToHost, M.stream));
         if (pitch) ZV_HIP(hipMemcpyAsync(pitch, t.pitch, b_ids, hipMemcpyDeviceToHost, M.stream));
@@ -132,15 +161,15 @@ zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts,
 zv_status zv_encode(zv_model *m, const int32_t *ids, const int32_t *puncts, const float *style, uint32_t n, uint32_t T,
                     float *hidden, uint32_t *n_frames)
 {
-    return zv_encode_taps(m, ids, puncts, style, n, T, hidden, n_frames, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return zv_encode_taps(m, ids, puncts, style, n, n, T, hidden, n_frames, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32_t T, float *mel)
 {
     return guarded([&] {
         ZV_NEED(m && hidden && style && mel, "null argument");
-        ZV_NEED(T > 0, "T must be > 0");
         Model &M = *m->m;
+        check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         const size_t E = M.E(), Mm = M.hp.audio_num_mels;
         const size_t b_hid = (size_t)T * E * 4, b_sty = (E * 4 + 255) & ~(size_t)255, b_mel = (size_t)T * Mm * 4;
@@ -148,7 +177,7 @@ zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32
         float *d_sty = (float *)io, *d_hid = (float *)(io + b_sty), *d_mel = (float *)(io + b_sty + ((b_hid + 255) & ~(size_t)255));
         ZV_HIP(hipMemcpyAsync(d_hid, hidden, b_hid, hipMemcpyHostToDevice, M.stream));
         ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
-        M.decode_dev(d_hid, d_sty, T, d_mel);
+        M.decode_dev(zv::Batch::single(1, T, 1), d_hid, d_sty, d_mel);
         ZV_HIP(hipMemcpyAsync(mel, d_mel, b_mel, hipMemcpyDeviceToHost, M.stream));
         M.sync();
     });
@@ -158,14 +187,14 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
 {
     return guarded([&] {
         ZV_NEED(m && mel && wav, "null argument");
-        ZV_NEED(T > 0, "T must be > 0");
         Model &M = *m->m;
+        check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         const size_t b_mel = ((size_t)T * M.hp.audio_num_mels * 4 + 255) & ~(size_t)255, b_wav = (size_t)T * M.hp.audio_hop_size * 4;
         char *io = (char *)M.io_scratch(b_mel + b_wav);
         float *d_mel = (float *)io, *d_wav = (float *)(io + b_mel);
         ZV_HIP(hipMemcpyAsync(d_mel, mel, (size_t)T * M.hp.audio_num_mels * 4, hipMemcpyHostToDevice, M.stream));
-        M.vocode_dev_graph(d_mel, T, d_wav);
+        M.vocode_dev_graph(zv::Batch::single(1, T, 1), d_mel, d_wav);
         ZV_HIP(hipMemcpyAsync(wav, d_wav, b_wav, hipMemcpyDeviceToHost, M.stream));
         M.sync();
     });
@@ -184,6 +213,7 @@ zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t c
         const size_t Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
         const uint32_t H = M.vocoder_halo_frames();
         const uint32_t ctx_max = std::min<uint64_t>(T, (uint64_t)chunk_frames + 2 * H);
+        check_T(M, ctx_max);                          // only a chunk plus its context is ever vocoded at once
         const size_t b_mel = ((size_t)T * Mm * 4 + 255) & ~(size_t)255, b_wav = (size_t)ctx_max * hop * 4;
         M.reserve(1, ctx_max);
         char *io = (char *)M.io_scratch(b_mel + b_wav);
@@ -210,7 +240,7 @@ zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t c
                 const uint32_t b = std::min<uint64_t>(T, (uint64_t)a + chunk_frames);
                 const uint32_t c0 = a > H ? a - H : 0, c1 = std::min<uint64_t>(T, (uint64_t)b + H);
                 deliver(k);                                   // the slot we are about to overwrite
-                M.vocode_dev(d_mel + (size_t)c0 * Mm, c1 - c0, d_wav);
+                M.vocode_dev(zv::Batch::single(1, c1 - c0, 1), d_mel + (size_t)c0 * Mm, d_wav);
                 ZV_HIP(hipMemcpyAsync(pin + k * slot, d_wav + (size_t)(a - c0) * hop, (size_t)(b - a) * hop * 4, hipMemcpyDeviceToHost, M.stream));
                 ZV_HIP(hipEventRecord(done[k], M.stream));
                 pend[k] = {true, (uint64_t)a * hop, (uint64_t)(b - a) * hop};
@@ -237,6 +267,7 @@ static void synthesize_enqueue(Model &M, const int32_t *ids, const int32_t *punc
                                float *wav, int32_t *nf_host)
 {
     check_ids(M, ids, puncts, n);
+    check_T(M, T);
     const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_ids = al((size_t)n * 4), b_sty = al(E * 4), b_hid = al((size_t)T * E * 4), b_mel = al((size_t)T * Mm * 4),
@@ -251,7 +282,7 @@ static void synthesize_enqueue(Model &M, const int32_t *ids, const int32_t *punc
     ZV_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
     ZV_HIP(hipMemcpyAsync(d_pun, puncts, (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
     ZV_HIP(hipMemcpyAsync(d_sty, style, E * 4, hipMemcpyHostToDevice, M.stream));
-    M.chain_dev(d_ids, d_pun, d_sty, n, T, d_hid, d_mel, d_wav, d_nf);
+    M.chain_dev(zv::Batch::single(n, T, n), d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf);
     ZV_HIP(hipMemcpyAsync(nf_host, d_nf, 4, hipMemcpyDeviceToHost, M.stream));
     ZV_HIP(hipMemcpyAsync(wav, d_wav, (size_t)T * hop * 4, hipMemcpyDeviceToHost, M.stream));
 }
@@ -272,6 +303,26 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
     });
 }
 
+// copies the finished waveforms out of the pinned staging block, on a few threads when there is enough to move
+static void scatter_out(const char *pin_wav, const size_t *off, float *const *wav, const uint32_t *T, size_t hop, uint32_t a, uint32_t b)
+{
+    size_t total = 0;
+    for (uint32_t u = a; u < b; u++) total += (size_t)T[u] * hop * 4;
+    const unsigned nth = total > ((size_t)8 << 20) ? 4u : 1u;
+    auto work = [&](unsigned k) {
+        for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u - a], (size_t)T[u] * hop * 4);
+    };
+    if (nth == 1)
+    {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nth; k++) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+}
+
 zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
                               const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T, float *const *wav,
                               uint32_t *n_frames)
@@ -280,39 +331,88 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
         ZV_NEED(m && ids && puncts && styles && n_phonemes && T && wav, "null argument");
         Model &M = *m->m;
         ZV_HIP(hipSetDevice(M.device));
+        M.select_lane(0);
         for (uint32_t u = 0; u < n_utt; u++)
         {
             ZV_NEED(ids[u] && puncts[u] && styles[u] && wav[u], "null utterance pointer");
             ZV_NEED(n_phonemes[u] > 0 && T[u] > 0, "n and T must be > 0");
+            check_T(M, T[u]);
+            check_ids(M, ids[u], puncts[u], n_phonemes[u]);
         }
-        // outputs land in pinned staging first: a D2H copy into the caller's pageable buffers would block the host
-        // until the utterance has finished and the lanes would run one after the other
-        const size_t hop = M.hp.audio_hop_size;
-        std::vector<size_t> off(n_utt + 1, 0);
-        for (uint32_t u = 0; u < n_utt; u++) off[u + 1] = off[u] + (((size_t)T[u] * hop * 4 + 255) & ~(size_t)255);
-        char *pin = (char *)M.pinned_scratch(off[n_utt] + (size_t)n_utt * 4 + 256);
-        int32_t *nf = (int32_t *)(pin + off[n_utt]);
-        const int lanes = n_utt < 4 ? (int)(n_utt ? n_utt : 1) : 4;
-        try
+        const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        // Groups of up to 64 utterances / 64 Ki frames go through the chain as ONE launch per kernel: every tensor is
+        // the row concatenation of the group, the segment tables tell the kernels where each utterance starts and ends.
+        // Capacities are rounded up so that batches of similar shape replay the same captured graph.
+        uint32_t a = 0;
+        while (a < n_utt)
         {
-            for (uint32_t u = 0; u < n_utt; u++)
+            uint32_t b = a, nmax = 0, tmax = 0;
+            while (b < n_utt && b - a < 64)
             {
-                M.select_lane((int)(u % lanes));
-                synthesize_enqueue(M, ids[u], puncts[u], styles[u], n_phonemes[u], T[u], (float *)(pin + off[u]), &nf[u]);
+                const uint32_t nm = std::max(nmax, n_phonemes[b]), tm = std::max(tmax, T[b]);
+                if (b > a && (uint64_t)(b - a + 1) * zv::round_up((int)tm, 64) > 65536) break;
+                nmax = nm;
+                tmax = tm;
+                b++;
             }
-        }
-        catch (...)
-        {
-            try { M.sync_all_lanes(); } catch (...) {}
-            M.select_lane(0);
-            throw;
-        }
-        M.sync_all_lanes();
-        M.select_lane(0);
-        for (uint32_t u = 0; u < n_utt; u++)
-        {
-            memcpy(wav[u], pin + off[u], (size_t)T[u] * hop * 4);
-            if (n_frames) n_frames[u] = (uint32_t)nf[u];
+            zv::Batch bt;
+            bt.nseg = (int)(b - a);
+            bt.n_max = zv::round_up((int)nmax, 32);
+            bt.t_max = zv::round_up((int)tmax, 64);
+            bt.n_rows = (size_t)bt.nseg * bt.n_max;
+            bt.t_rows = (size_t)bt.nseg * bt.t_max;
+            // device block: [frame counts][inputs: token table | frame table | ids | puncts | styles][hidden][mel][wav]
+            const size_t b_tab = al((size_t)bt.nseg * sizeof(zv::Seg)), b_ids = al(bt.n_rows * 4), b_sty = al((size_t)bt.nseg * E * 4);
+            const size_t b_in = 2 * b_tab + 2 * b_ids + b_sty;
+            const size_t b_nf = al((size_t)bt.nseg * 4), b_hid = al(bt.t_rows * E * 4), b_mel = al(bt.t_rows * Mm * 4),
+                         b_wav = al(bt.t_rows * hop * 4);
+            M.reserve_batch(bt);
+            char *io = (char *)M.io_scratch(b_nf + b_in + b_hid + b_mel + b_wav);
+            int32_t *d_nf = (int32_t *)io;
+            char *d_in = io + b_nf;
+            zv::Seg *d_tok = (zv::Seg *)d_in, *d_frm = (zv::Seg *)(d_in + b_tab);
+            int32_t *d_ids = (int32_t *)(d_in + 2 * b_tab), *d_pun = (int32_t *)(d_in + 2 * b_tab + b_ids);
+            float *d_sty = (float *)(d_in + 2 * b_tab + 2 * b_ids);
+            float *d_hid = (float *)(d_in + b_in), *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
+            bt.d_tok = d_tok;
+            bt.d_frm = d_frm;
+            // pinned mirror of the input block + landing area of the results
+            size_t wav_bytes = 0;
+            std::vector<size_t> woff(bt.nseg);
+            for (uint32_t u = a; u < b; u++)
+            {
+                woff[u - a] = wav_bytes;
+                wav_bytes += (size_t)T[u] * hop * 4;
+            }
+            char *pin = (char *)M.pinned_scratch(b_in + b_nf + al(wav_bytes));
+            {
+                zv::Seg *h_tok = (zv::Seg *)pin, *h_frm = (zv::Seg *)(pin + b_tab);
+                int32_t *h_ids = (int32_t *)(pin + 2 * b_tab), *h_pun = (int32_t *)(pin + 2 * b_tab + b_ids);
+                float *h_sty = (float *)(pin + 2 * b_tab + 2 * b_ids);
+                int32_t n0 = 0, t0 = 0;
+                for (uint32_t u = a; u < b; u++)
+                {
+                    const int32_t n = (int32_t)n_phonemes[u], t = (int32_t)T[u];
+                    h_tok[u - a] = zv::Seg{n0, n, n, 0};
+                    h_frm[u - a] = zv::Seg{t0, t, 0, 0};
+                    memcpy(h_ids + n0, ids[u], (size_t)n * 4);
+                    memcpy(h_pun + n0, puncts[u], (size_t)n * 4);
+                    memcpy(h_sty + (size_t)(u - a) * E, styles[u], E * 4);
+                    n0 += n;
+                    t0 += t;
+                }
+            }
+            M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
+            int32_t *h_nf = (int32_t *)(pin + b_in);
+            char *h_wav = pin + b_in + b_nf;
+            ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+            ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
+            M.sync();
+            scatter_out(h_wav, woff.data(), wav, T, hop, a, b);
+            if (n_frames)
+                for (uint32_t u = a; u < b; u++) n_frames[u] = (uint32_t)h_nf[u - a];
+            a = b;
         }
     });
 }
@@ -364,8 +464,9 @@ zv_status zv_vocode_device(zv_model *m, const float *d_mel, uint32_t T, float *d
 {
     return guarded([&] {
         ZV_NEED(m && d_mel && d_wav, "null argument");
+        check_T(*m->m, T);
         ZV_HIP(hipSetDevice(m->m->device));
-        m->m->vocode_dev_graph(d_mel, T, d_wav);
+        m->m->vocode_dev_graph(zv::Batch::single(1, T, 1), d_mel, d_wav);
     });
 }
 
@@ -373,8 +474,9 @@ zv_status zv_decode_device(zv_model *m, const float *d_hidden, const float *d_st
 {
     return guarded([&] {
         ZV_NEED(m && d_hidden && d_style && d_mel, "null argument");
+        check_T(*m->m, T);
         ZV_HIP(hipSetDevice(m->m->device));
-        m->m->decode_dev(d_hidden, d_style, T, d_mel);
+        m->m->decode_dev(zv::Batch::single(1, T, 1), d_hidden, d_style, d_mel);
     });
 }
 
@@ -475,6 +577,7 @@ zv_status zv_write_wav(const char *path, const float *wav, size_t n_samples, uin
         ZV_NEED(path && wav, "null argument");
         FILE *f = fopen(path, "wb");
         if (!f) zv::fail(ZV_ERR_IO, "cannot open '%s' for writing", path);
+        if (n_samples > (size_t)0x7FFFFFE0u / 2) zv::fail(ZV_ERR_ARG, "%zu samples do not fit a RIFF/WAVE file (32-bit sizes)", n_samples);
         const uint32_t data_bytes = (uint32_t)(n_samples * 2);
         uint8_t hdr[44];
         auto put32 = [&](int o, uint32_t v) { for (int i = 0; i < 4; i++) hdr[o + i] = (uint8_t)(v >> (8 * i)); };

@@ -80,8 +80,17 @@ __device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : 
 // ---- stage: HBM -> prologue -> f16 -> LDS.  U independent 16-byte loads per thread are issued before any of
 // them is consumed (hipcc otherwise waits vmcnt(0) after every load and the tile fill becomes a chain of
 // full HBM latencies).  LDS row r holds input time row_t0 + r; out-of-range rows are zeros.
+// what the staging loop reads: the job's input with every pointer already advanced to the workgroup's segment
+struct StageSrc
+{
+    const void  *x0, *x1, *x2;
+    const float *pa, *pb, *pstat;
+    int          ldx, L;
+    float        slope, pscale;
+};
+
 template <int U, int PRO, int NTH = 256>
-__device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
+__device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
                                              int tid)
 {
     const int cols = ck >> 2;
@@ -181,10 +190,10 @@ __device__ __forceinline__ void stage_tile_p(const ConvJob &J, char *smem, int R
 }
 
 template <int U, int NTH = 256>
-__device__ __forceinline__ void stage_tile(const ConvJob &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
+__device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
                                            int tid)
 {
-    switch (J.pro)      // wave-uniform; each case is a straight-line batched fill
+    switch (pro)        // wave-uniform; each case is a straight-line batched fill
     {
         case PRO_RAW_F16: stage_tile_p<U, PRO_RAW_F16, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         case PRO_ACT: stage_tile_p<U, PRO_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
@@ -262,16 +271,13 @@ __device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT][NT], const half8 (
 // one step ahead.  All LDS and weight addresses inside a body are immediates off the body's base.  A wave covers
 // NT output tiles of 32 channels (their weight segments are `wseg` half8 apart) and MT row tiles.
 template <int CP, int MT, int NT, bool SWAP>
-__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K,
-                                          int ib0 = 0, int ib1 = -1)
+__device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
 {
-    // [ib0, ib1): the bodies this wave runs (split-K callers hand every wave a slice and pass ap / wq already
-    // advanced to body ib0); the default is the whole contraction
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;        // taps per body: 4 / 2 / 1 / (1/2) for CP = 32 / 64 / 128 / 256
     constexpr bool HALF = NKC == 16;                     // CP = 256: a tap is two bodies (channels 0-127, 128-255)
     const int nsb = (K * NKC + 3) >> 2;                  // 4-step sub-blocks (the last one may run partly on zero weights)
-    const int nb = ib1 < 0 ? (nsb >> 1) : ib1;
+    const int nb = nsb >> 1;
     half8 b0[4][NT], b1[4][NT];
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -288,7 +294,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
         const char *np_ = ZV_A_ADDR(un);                                                     \
         _Pragma("unroll") for (int mt = 0; mt < MT; mt++) dst[mt] = *(const half8 *)(np_ + mt * 32 * RS); \
     }
-    for (int ib = ib0; ib < nb; ib++)
+    for (int ib = 0; ib < nb; ib++)
     {
         const char *tb[4];
         tb[0] = ap;
@@ -316,7 +322,7 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
         ap = apn;
         wq += 8 * 64;
     }
-    if (ib1 < 0 && (nsb & 1))                    // odd sub-block count (CP = 64): one more tap on b0
+    if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
     {
         const char *tb[4] = {ap, ap, ap, ap};
         const char *apn = ap;
@@ -413,16 +419,38 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
 #undef ZV_UN8
 }
 
+// f64 partial sums of a wave's 32 x 32 output tile per channel (= lane & 31): the lane's 16 rows in register order, then
+// the two half-waves (rows 4*(lane>>5) + ...); rows at or past L do not count.  See launch_stats_finalize.
+__device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_first, int L, double *dst)
+{
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        const int t = t_first + (r & 3) + 8 * (r >> 2);
+        const double x = (t < L) ? (double)v[r] : 0.0;
+        s1 += x;
+        s2 += x * x;
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if ((threadIdx.x & 63) < 32) *(double2 *)dst = make_double2(s1, s2);
+}
+
 template <int MT, int WN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     const ConvJob &J = jobs.j[blockIdx.z];
 
-    const int L = J.L;
-    const int m0 = blockIdx.x * BM;
+    // workgroup -> (segment, row tile inside the segment)
+    const int useg = blockIdx.x / jobs.tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int m0 = (blockIdx.x - useg * jobs.tps) * BM;
     if (m0 >= L) return;
+    const size_t row0 = (size_t)sg.row0 * jobs.rate;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -439,6 +467,21 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     const int rows = BM + (K - 1) * dil;
     const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
 
+    StageSrc S;
+    {
+        const size_t xo = row0 * J.ldx * (J.pro == PRO_RAW_F16 ? 2 : 4);
+        S.x0 = (const char *)J.x0 + xo;
+        S.x1 = J.x1 ? (const char *)J.x1 + xo : nullptr;
+        S.x2 = J.x2 ? (const char *)J.x2 + xo : nullptr;
+        S.pa = J.pa ? J.pa + (size_t)useg * J.pab_seg : nullptr;
+        S.pb = J.pb ? J.pb + (size_t)useg * J.pab_seg : nullptr;
+        S.pstat = J.pstat ? J.pstat + (size_t)useg * J.pstat_seg : nullptr;
+        S.ldx = J.ldx;
+        S.L = L;
+        S.slope = J.slope;
+        S.pscale = J.pscale;
+    }
+
     floatx16 acc[MT][1];
 #pragma unroll
     for (int i = 0; i < MT; i++)
@@ -451,22 +494,15 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
-        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         __syncthreads();
         if (n_ok && !(J.dbg & 2))
         {
             const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
-            // full chunks of 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there and
-            // the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
-            // (the 256-channel instantiation is kept to MT = 1: with taller tiles it pushed the whole kernel to 176 VGPRs)
-            bool done256 = false;
-            if constexpr (MT == 1)
-                if (ck == 256 && J.ck == 256)
-                {
-                    mfma_taps<256, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
-                    done256 = true;
-                }
-            if (done256) {}
+            // full chunks of 256 / 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there
+            // and the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
+            if (ck == 256 && J.ck == 256)
+                mfma_taps<256, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
             else if (ck == 128 && J.ck == 128)
                 mfma_taps<128, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
             else if (ck == 64 && J.ck == 64)
@@ -484,6 +520,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
     const float escale = J.escale;
     const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
     const bool has_res = J.res != nullptr;
+    const float *res = has_res ? J.res + row0 * J.ldres : nullptr;
+    const size_t out0 = row0 * J.ldo;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
     {
@@ -494,171 +532,45 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvJobs jobs)
             for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
             {
                 const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                resv[r] = J.res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+                resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
             }
         }
+        float outv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
             const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[mt][0][r] + bias;
+            if (has_res) v = v + resv[r];
+            v = v * escale;
+            if (J.eact) v = lrelu(v, J.oslope);
+            outv[r] = v;
             if (t < L)
             {
-                float v = acc[mt][0][r] + bias;
-                if (has_res) v = v + resv[r];
-                v = v * escale;
-                if (J.eact) v = lrelu(v, J.oslope);
                 if (J.out_f16)
-                    ((_Float16 *)J.out)[(size_t)t * J.ldo + oc] = (_Float16)v;
+                    ((_Float16 *)J.out)[out0 + (size_t)t * J.ldo + oc] = (_Float16)v;
                 else
-                    ((float *)J.out)[(size_t)t * J.ldo + oc] = v;
+                    ((float *)J.out)[out0 + (size_t)t * J.ldo + oc] = v;
             }
         }
-    }
-}
-
-// ---- split-K variant for short sequences.  A conv over T = 512 decoder frames has 16 x 33 output tiles of 32 x 32:
-// the plain kernel gives that 144 workgroups, most CUs run one wave per SIMD and that wave waits out every LDS and
-// L2 latency of its (tap, channel) chain alone.  Here a workgroup of NWV waves owns BM = 32*MT rows x NW output
-// tiles of ONE job; the KS = NWV / NW waves that share a tile split the contraction of every 256-channel chunk, the
-// partial sums meet in LDS (fixed order: deterministic) and each of the KS waves finishes 1/KS of the tile's rows
-// (bias, residual, activation, store).  NW is chosen per job by the launcher from the jobs' shapes only (never from
-// L: the summation order of an output element must not depend on the utterance length) so that the workgroups of
-// unequal jobs stream about the same number of weight bytes.
-// Measured (profiles/r01_v5_*): decoder chain 1.98 -> 1.84 ms.  HiFi-GAN stage 1 (2 560 rows, jobs of 3 / 7 / 11
-// taps) does NOT gain: there the plain kernel's 480 workgroups are bound by the matrix pipe at the clock the chip
-// holds under MFMA load plus the imbalance between the 3-tap and 11-tap workgroups (phase ablation: MFMA phase 9.7 us
-// whether the weights come from L2 or sit in L1, with 4 or 8 waves per tile, MT = 1 or 2), so it stays on the plain
-// kernel.
-template <int NWV, int MT>
-__global__ __launch_bounds__(64 * NWV) void conv1d_splitk_kernel(const ConvJobs jobs)
-{
-    constexpr int NTH = 64 * NWV, BM = 32 * MT, NR = 16 * MT;
-    const ConvJob &J = jobs.j[blockIdx.z];
-    const int L = J.L;
-    const int m0 = blockIdx.x * BM;
-    const int lg_nw = J.sk_lg_nw, NW = 1 << lg_nw, KS = NWV >> lg_nw;
-    const int Cout_p = J.Cout_p;
-    const int ntiles = (Cout_p + 31) >> 5;
-    if (m0 >= L || (int)(blockIdx.y << lg_nw) >= ntiles) return;      // grid.y is sized for the job with the smallest NW
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ks = wave >> lg_nw, wn = wave & (NW - 1);
-
-    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p;
-    const int nicb = Cin_p >> 4;
-    const int nt = (blockIdx.y << lg_nw) + wn;
-    const bool n_ok = nt < ntiles;
-    const int rows = BM + (K - 1) * dil;
-    const int RS = J.ck * 2 + 16;
-
-    floatx16 acc[MT][1];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
-    const char *abase = smem + (lane & 31) * RS + (lane >> 5) * 16;
-    const int nb = 2 * K, ib0 = ks * nb / KS, ib1 = (ks + 1) * nb / KS;      // bodies of half a tap (128 channels)
-
-    for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
-    {
-        const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-        if (c0) __syncthreads();
-        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U, NTH>(J, smem, RS, c0, ck, m0 - J.pad, rows, tid);
-        __syncthreads();
-        if (n_ok && !(J.dbg & 2))
+        if (J.stat_part && oc < J.stat_C)
         {
-            const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
-            if (ck == 256)
-                mfma_taps<256, MT, 1, false>(acc, abase + (ib0 >> 1) * dil * RS + (ib0 & 1) * 256, dil * RS,
-                                             wp + (size_t)ib0 * 8 * 64, 0, K, ib0, ib1);
-            else if (ks == KS - 1)           // remainder chunk (< 256 channels)
-                mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
+            const int blk = (m0 >> 5) + wm * MT + mt;                  // 32-row block of the segment
+            if (blk * 32 < L)
+                tile_stats_store(outv, tbase + mt * 32, L, J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc) * 2);
         }
     }
-
-    // ---- partial sums meet in LDS: red[slice][tile][register][lane]
-    __syncthreads();                          // the input tile is dead: its LDS becomes the exchange area
-    float *red = (float *)smem;
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) red[(((ks << lg_nw) + wn) * NR + mt * 16 + r) * 64 + lane] = acc[mt][0][r];
-    __syncthreads();
-    if (!n_ok || (J.dbg & 4)) return;
-
-    // ---- epilogue: wave ks finishes accumulator registers [ks*RPW, (ks+1)*RPW) of its tile, four at a time
-    const int oc = nt * 32 + (lane & 31);
-    if (oc >= Cout_p) return;
-    const float bias = J.bias ? J.bias[oc] : 0.f;
-    const float escale = J.escale;
-    const bool has_res = J.res != nullptr;
-    const int RPW = NR / KS;                  // >= 4 (launcher)
-    const float *rp = red + (wn * NR) * 64 + lane;
-    const int kstride = (NR << lg_nw) * 64;
-    for (int i0 = ks * RPW; i0 < (ks + 1) * RPW; i0 += 4)
-    {
-        int t[4];
-        float resv[4], v[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            const int idx = i0 + i, r = idx & 15;
-            t[i] = m0 + (idx >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            resv[i] = has_res ? J.res[(size_t)(t[i] < L ? t[i] : L - 1) * J.ldres + oc] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            float sum = rp[(i0 + i) * 64];
-            for (int k = 1; k < KS; k++) sum += rp[k * kstride + (i0 + i) * 64];
-            v[i] = sum;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            if (t[i] >= L) continue;
-            float x = v[i] + bias;
-            if (has_res) x = x + resv[i];
-            x = x * escale;
-            if (J.eact) x = lrelu(x, J.oslope);
-            if (J.out_f16)
-                ((_Float16 *)J.out)[(size_t)t[i] * J.ldo + oc] = (_Float16)x;
-            else
-                ((float *)J.out)[(size_t)t[i] * J.ldo + oc] = x;
-        }
-    }
-}
-
-template <int NWV, int MT>
-static hipError_t launch_splitk_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int ny, int halo, int ck, int dmax_)
-{
-    constexpr int BM = 32 * MT;
-    dim3 grid((Lmax + BM - 1) / BM, ny, njobs);
-    size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);
-    const size_t red = (size_t)NWV * MT * 16 * 64 * 4;
-    if (red > lds) lds = red;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_splitk_kernel<NWV, MT>;
-    if (lds > 64 * 1024)
-    {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, jobs);
-    return hipGetLastError();
 }
 
 template <int MT, int WN>
-static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int K, int dil, int ck, int dmax_)
+static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int halo, int ck, int dmax_)
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     const int ntiles = (Cout_p + 31) / 32;
-    dim3 grid((Lmax + BM - 1) / BM, (ntiles + WN - 1) / WN, njobs);
-    const size_t lds = (size_t)(BM + (K - 1) * dil + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
+    jobs.tps = (Lmax + BM - 1) / BM;
+    dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN - 1) / WN, njobs);
+    const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv1d_mfma_kernel<MT, WN>;
     if (lds > 64 * 1024)
@@ -670,34 +582,36 @@ static hipError_t launch_cfg(hipStream_t s, const ConvJobs &jobs, int njobs, int
     return hipGetLastError();
 }
 
-hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
+hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
-    if (njobs < 1 || njobs > CONV_MAX_JOBS) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > CONV_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
     ConvJobs js;
-    int Lmax = 0, Kmax = 0, halo = 0, ck = 0, dmax = 1;
+    js.segs = segs;
+    js.rate = rate;
+    js.tps = 0;
+    const int Lmax = segs.max_rows * rate;
+    int halo = 0, ck = 0, dmax = 1;
     for (int i = 0; i < njobs; i++)
     {
         js.j[i] = jobs[i];
         dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
         js.j[i].dbg = dbg;
         if (jobs[i].Cout_p != jobs[0].Cout_p) return hipErrorInvalidValue;
-        Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
         const int h = (jobs[i].K - 1) * jobs[i].dil;
-        if (h > halo) { halo = h; Kmax = jobs[i].K; }
+        if (h > halo) halo = h;
         ck = jobs[i].ck > ck ? jobs[i].ck : ck;
+        if (jobs[i].stat_part && jobs[i].stat_nblk * 32 < Lmax) return hipErrorInvalidValue;
     }
-    for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = jobs[0];
-    // launch_cfg sizes LDS from (K-1)*dil: pass the job with the largest halo as (K, dil) = (halo+1, 1)
-    (void)Kmax;
-    const int Kh = halo + 1;
+    for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     const int Cout_p = jobs[0].Cout_p;
     const int ntiles = (Cout_p + 31) / 32;
     const int WN = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
-    // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups
+    // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups; the tile
+    // height never changes an output bit: every output element is one accumulator chain over (chunk, tap, channel)
     auto wgs = [&](int MT) {
         const int BM = 32 * MT * (4 / WN);
-        return (long)((Lmax + BM - 1) / BM) * ((ntiles + WN - 1) / WN) * njobs;
+        return (long)((Lmax + BM - 1) / BM) * segs.nseg * ((ntiles + WN - 1) / WN) * njobs;
     };
     int MT = 4;
     while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
@@ -706,48 +620,8 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu)
         static const char *e_mt = getenv("ZV_CONV_MT");
         if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
     }
-    {   // short sequences over 256-channel chunks: conv1d_splitk_kernel, workgroup shapes balanced per job
-        const int e_sk = getenv("ZV_SPLITK") ? atoi(getenv("ZV_SPLITK")) : -1;      // 0 = off, else MT (1 | 2)
-        bool ok = ck == 256 && ntiles >= 4;
-        for (int i = 0; i < njobs; i++) ok = ok && jobs[i].ck == 256 && jobs[i].Cin_p >= 256 && jobs[i].allow_splitk;
-        // measured (MI355X, medium geometry): the decoder's 512-row convs (144 plain workgroups) run 7 % faster per
-        // chain on the split kernel, HiFi-GAN stage 1 (480 plain workgroups, three unequal jobs) does not
-        // only jobs that allow it (decoder / encoder convs): the vocoder stays on the plain kernel at every length, so
-        // that its output bits never depend on the sequence length (zv_vocode_stream)
-        int smt = (ok && wgs(1) < (long)n_cu) ? 1 : 0;
-        if (e_sk >= 0 && ok) smt = e_sk;
-        if (smt == 1 || smt == 2)
-        {
-            constexpr int NWV = 8;
-            const int lg_min = smt == 1 ? 1 : 0;             // the epilogue hands each wave >= 4 accumulator registers
-            // Output tiles per workgroup, per job: the heaviest job (most weight bytes per tile) gets one tile per
-            // workgroup and all 8 waves on its contraction, lighter jobs the power of two that brings their
-            // workgroups closest to the same weight traffic.  A function of the jobs' shapes only, never of L: the
-            // summation order of an output element must not depend on the utterance length.
-            int lg[CONV_MAX_JOBS];
-            long cmax = 0;
-            for (int i = 0; i < njobs; i++) cmax = std::max(cmax, (long)jobs[i].K * jobs[i].Cin_p);
-            for (int i = 0; i < njobs; i++)
-            {
-                const double ratio = (double)cmax / ((double)jobs[i].K * jobs[i].Cin_p);
-                int l = lg_min;
-                while (l < 3 && ratio >= 1.4142135623730951 * (double)(1 << (l - lg_min))) l++;
-                lg[i] = l > 3 ? 3 : l;
-            }
-            int ny = 1;
-            for (int i = 0; i < njobs; i++)
-            {
-                js.j[i].sk_lg_nw = lg[i];
-                const int y = (ntiles + (1 << lg[i]) - 1) >> lg[i];
-                ny = y > ny ? y : ny;
-            }
-            for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i].sk_lg_nw = lg[0];
-            if (smt == 1) return launch_splitk_cfg<NWV, 1>(s, js, njobs, Lmax, ny, halo, ck, dmax);
-            return launch_splitk_cfg<NWV, 2>(s, js, njobs, Lmax, ny, halo, ck, dmax);
-        }
-    }
 #define ZV_CASE(mt, wn) \
-    if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, Kh, 1, ck, dmax);
+    if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
     ZV_CASE(4, 4) ZV_CASE(2, 4) ZV_CASE(1, 4)
     ZV_CASE(4, 2) ZV_CASE(2, 2) ZV_CASE(1, 2)
     ZV_CASE(4, 1) ZV_CASE(2, 1) ZV_CASE(1, 1)
@@ -868,11 +742,22 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     constexpr int BM = 32 * MT * WM;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     const PairJob &P = jobs.j[blockIdx.z];
-    const int L = P.L, K = P.K, dil = P.dil;
+    const int K = P.K, dil = P.dil;
     const int h2 = (K - 1) / 2, h1 = h2 * dil;
     const int TM = BM - 2 * h2;
-    const int t0 = zv_xcd_tile(blockIdx.x, (L + TM - 1) / TM) * TM;
+    // workgroup -> (segment, time tile): every segment gets the tile count of the longest one, tiles past a segment's
+    // end exit; the XCD map runs over the whole (segment, tile) range, so an XCD works on neighbouring tiles of
+    // neighbouring utterances
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -883,7 +768,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
 
     // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)P.y, 0, L * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
     if (!(P.dbg & 1)) stage_act_buf<ZV_STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
     __syncthreads();
 
@@ -949,8 +834,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
     if (P.dbg & 4) return;
     const int nrows = (L - t0 < TM) ? (L - t0) : TM;
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(P.y + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(P.out + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
     {
@@ -982,7 +867,7 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     const int TMmin = BM - (Kmax - 1);
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
-    dim3 grid(round_up((Lmax + TMmin - 1) / TMmin, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
+    dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil
     const size_t lds = (size_t)(BM + (Kmax + 4) * dmax) * (CP * 2 + 16);
     auto kern = resblock_pair_kernel<CP, MT>;
@@ -995,19 +880,21 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     return hipGetLastError();
 }
 
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
-    if (njobs < 1 || njobs > PAIR_MAX_JOBS) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
     static const int mt_env = getenv("ZV_PAIR_MT") ? atoi(getenv("ZV_PAIR_MT")) : 0;
     PairJobs js;
-    int Lmax = 0, Kmax = 0, dmax = 0;
+    js.segs = segs;
+    js.rate = rate;
+    const int Lmax = segs.max_rows * rate;
+    int Kmax = 0, dmax = 0;
     for (int i = 0; i < njobs; i++)
     {
         js.j[i] = jobs[i];
         js.j[i].dbg = dbg;
         if (jobs[i].Cp != jobs[0].Cp) return hipErrorInvalidValue;
-        Lmax = jobs[i].L > Lmax ? jobs[i].L : Lmax;
         Kmax = jobs[i].K > Kmax ? jobs[i].K : Kmax;
         dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
     }
@@ -1017,7 +904,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu)
     auto wgs = [&](int MT) {
         const int BM = 32 * MT * (4 / WN);
         const int TM = BM - (Kmax - 1);
-        return TM < 32 ? 0L : (long)((Lmax + TM - 1) / TM) * njobs;
+        return TM < 32 ? 0L : (long)((Lmax + TM - 1) / TM) * segs.nseg * njobs;
     };
     // tallest tile that still gives every CU about three workgroups, but never a BM so small that the
     // (k-1)-row halo dominates (MT >= 2: BM >= 64 / 128 / 256 for 128 / 64 / 32 channels)
@@ -1059,14 +946,22 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     static_assert(CP == 32, "one 32-channel output tile per wave");
     const TripleJob &P = jobs.j[blockIdx.z];
-    const int L = P.L, K = P.K, nd = P.n_dil;
+    const int K = P.K, nd = P.n_dil;
     const int h2 = (K - 1) / 2;
     int sumd = 0, dmax = 1;
     for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
     const int H = h2 * (sumd + nd);
     const int TM = R - 2 * H;
-    const int t0 = zv_xcd_tile(blockIdx.x, (L + TM - 1) / TM) * TM;
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;      // (segment, tile) as in resblock_pair_kernel
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
     const int XM = h2 * dmax;
     const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
 
@@ -1083,7 +978,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
     for (int i = tid; i < xrows * RS / 16; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
     float yreg[MT][16];
     {
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)P.y, 0, L * CP * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
         const int voff = ((t0 - H + irow0) * CP + col) * 4;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -1169,7 +1064,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
     // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
     if (P.dbg & 4) return;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)P.out, 0, L * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -1190,17 +1085,18 @@ bool triple_supported(int Cp, int K, const int *dil, int n_dil)
     return 256 - (K - 1) * (sumd + n_dil) >= 96;          // at least 3/8 of the tile's rows are output
 }
 
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu)
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
-    if (njobs < 1 || njobs > PAIR_MAX_JOBS) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
     static const int cfg_env = getenv("ZV_TRIPLE_CFG") ? atoi(getenv("ZV_TRIPLE_CFG")) : 0;      // A/B hook: MT*1000 + R
     TripleJobs js;
-    // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once the sequence is
-    // long enough for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
-    int Lmax = 0;
-    for (int i = 0; i < njobs; i++) Lmax = std::max(Lmax, jobs[i].L);
-    int R = (long)Lmax * njobs >= 7000L * n_cu ? 512 : 256, MT = 2;
+    js.segs = segs;
+    js.rate = rate;
+    // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are enough rows
+    // for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
+    const int Lmax = segs.max_rows * rate;
+    int R = (long)Lmax * segs.nseg * njobs >= 7000L * n_cu ? 512 : 256, MT = 2;
     if (cfg_env) { MT = cfg_env / 1000; R = cfg_env % 1000; }
     int gx = 1;
     size_t lds = 0;
@@ -1213,7 +1109,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         int sumd = 0, dmax = 1;
         for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
         const int h2 = (P.K - 1) / 2, TM = R - 2 * h2 * (sumd + P.n_dil);
-        gx = std::max(gx, (P.L + TM - 1) / TM);
+        gx = std::max(gx, ((Lmax + TM - 1) / TM) * segs.nseg);
         const size_t rows = R + 2 * h2 * dmax + 5 * dmax;
         lds = std::max(lds, rows * (P.Cp * 2 + 16));
     }
@@ -1238,7 +1134,14 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const OutConvArgs a)
     const int RS = Cp * 2 + 16;
     const int K = a.K, pad = (K - 1) / 2;
     const int rows = 256 + K - 1;
-    const int m0 = blockIdx.x * 256;
+    const int tps = (a.segs.max_rows * a.rate + 255) >> 8;
+    const int useg = blockIdx.x / tps;
+    const Seg sg = seg_at(a.segs, useg);
+    const int L = sg.rows * a.rate;
+    const int m0 = (blockIdx.x - useg * tps) * 256;
+    if (m0 >= L) return;
+    const size_t row0 = (size_t)sg.row0 * a.rate;
+    const float *x0 = a.x0 + row0 * a.ldx, *x1 = a.x1 ? a.x1 + row0 * a.ldx : nullptr, *x2 = a.x2 ? a.x2 + row0 * a.ldx : nullptr;
     const int tid = threadIdx.x;
     _Float16 *wl = (_Float16 *)(smem + rows * RS);
     for (int i = tid; i < K * Cp; i += 256) wl[i] = ((const _Float16 *)a.w)[i];
@@ -1249,14 +1152,14 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const OutConvArgs a)
         const int r = idx / cols, c4 = idx - r * cols;
         const int t = m0 - pad + r;
         half4 h = {0, 0, 0, 0};
-        if (t >= 0 && t < a.L)
+        if (t >= 0 && t < L)
         {
             const size_t off = (size_t)t * a.ldx + c4 * 4;
-            float4 v = *(const float4 *)(a.x0 + off);
-            if (a.x1)
+            float4 v = *(const float4 *)(x0 + off);
+            if (x1)
             {
-                const float4 b = *(const float4 *)(a.x1 + off);
-                const float4 d = *(const float4 *)(a.x2 + off);
+                const float4 b = *(const float4 *)(x1 + off);
+                const float4 d = *(const float4 *)(x2 + off);
                 v.x = ((v.x + b.x) + d.x) * a.pscale;
                 v.y = ((v.y + b.y) + d.y) * a.pscale;
                 v.z = ((v.z + b.z) + d.z) * a.pscale;
@@ -1271,7 +1174,7 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const OutConvArgs a)
     }
     __syncthreads();
     const int t = m0 + tid;
-    if (t >= a.L) return;
+    if (t >= L) return;
     float acc = 0.f;
     for (int tap = 0; tap < K; tap++)
     {
@@ -1284,15 +1187,16 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const OutConvArgs a)
             for (int j = 0; j < 8; j++) acc = fmaf((float)x[j], (float)w[j], acc);
         }
     }
-    a.out[t] = tanhf(acc + a.bias);
+    a.out[row0 + t] = tanhf(acc + a.bias);
 }
 
 hipError_t launch_out_conv(hipStream_t s, const OutConvArgs &a)
 {
     const int Cp = round_up(a.C, 16);
     const size_t lds = (size_t)(256 + a.K - 1) * (Cp * 2 + 16) + (size_t)a.K * Cp * 2;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(out_conv_tanh_kernel, dim3((a.L + 255) / 256), dim3(256), lds, s, a);
+    if (lds > 64 * 1024 || a.segs.nseg < 1) return hipErrorInvalidValue;
+    const int tps = (a.segs.max_rows * a.rate + 255) / 256;
+    hipLaunchKernelGGL(out_conv_tanh_kernel, dim3(tps * a.segs.nseg), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -15,6 +15,42 @@ namespace zv
 
 __host__ __device__ static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
+// ---- segments: many utterances per launch ---------------------------------------------------------
+// A batch is laid out as ONE row-concatenated buffer per tensor: utterance u owns rows [row0, row0 + rows) (frames
+// for the decoder / vocoder, phonemes for the encoder).  Every kernel maps a workgroup to (segment, tile inside the
+// segment) and treats the segment's ends as the sequence ends (zero padding of the convs, InstanceNorm / attention
+// extents): each utterance keeps its own (N, T), exactly as if it had been run alone (reference
+// src/fs2encoder.cpp:103-110, src/stylettsdec.cpp:359: no masks, no batch padding).  The table lives in HBM, so one
+// captured hipGraph serves every batch that fits its capacity; a single utterance travels inline in the kernel
+// arguments (`one`) and needs no table.  `rate` (per launch) converts base rows to the rows of a stage
+// (HiFi-GAN stages: 1, 5, 25, 100, 300 samples per frame).
+struct Seg
+{
+    int32_t row0, rows;      // base units (frames or phonemes)
+    int32_t aux;             // encoder: num_phonemes the length regulator walks (reference src/fs2encoder.cpp:622)
+    int32_t pad;
+};
+struct Segs
+{
+    const Seg *tab;          // device table [nseg] or null
+    int        nseg;         // table entries; the grid covers all of them, empty ones (rows = 0) exit at once
+    int        max_rows;     // >= rows of every entry (grid sizing), base units
+    Seg        one;          // the segment when tab == null
+};
+__host__ __device__ static inline Seg seg_at(const Segs &s, int u) { return s.tab ? s.tab[u] : s.one; }
+static inline Segs segs_single(int rows, int aux = 0)
+{
+    Segs s;
+    s.tab = nullptr;
+    s.nseg = 1;
+    s.max_rows = rows;
+    s.one.row0 = 0;
+    s.one.rows = rows;
+    s.one.aux = aux;
+    s.one.pad = 0;
+    return s;
+}
+
 // ---- fused Conv1d ("same" length, stride 1) as implicit GEMM on v_mfma_f32_32x32x16_f16 -----------
 //
 //   out[t][oc] = epilogue( sum_{tap, ic} f16( prologue(x)[t + tap*dil - pad][ic] ) * w[tap][ic][oc] )
@@ -56,16 +92,21 @@ struct ConvJob
     void        *out;
     int          ldo;
     int          dbg;            // timing-only ablation bits (ZV_DBG env): 1 no staging loads, 2 no MFMA, 4 no epilogue
-    int          sk_lg_nw;       // split-K kernel: log2(output tiles per workgroup), filled in by launch_conv
-    int          allow_splitk;   // the caller accepts a sequence-length-dependent summation order (decoder / encoder
-                                 // convs: InstanceNorm / attention make those stages length-dependent anyway); the
-                                 // vocoder never sets it: its output bits must not depend on T (zv_vocode_stream)
+    // per-segment strides (floats) of the prologue's per-channel vectors: 0 = one vector for every segment
+    int          pstat_seg, pab_seg;
+    // InstanceNorm statistics of the OUTPUT, produced by the epilogue: per (segment, 32-row block, channel) the f64
+    // pair (sum, sum of squares) of the stored values, combined later in a fixed order by launch_stats_finalize
+    double      *stat_part;      // [nseg][stat_nblk][stat_C][2] or null
+    int          stat_nblk, stat_C;
 };
 
 constexpr int CONV_MAX_JOBS = 4;
 struct ConvJobs
 {
     ConvJob j[CONV_MAX_JOBS];
+    Segs    segs;
+    int     rate;                // rows per base row of this launch
+    int     tps;                 // row tiles per segment (grid.x = tps * nseg)
 };
 
 // bytes of one packed conv weight: [ntile32][chunk][tap][kc][lane 64][8 halfs]
@@ -74,8 +115,8 @@ size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K);
 int    conv_pick_ck(int Cin_p, int ck_max = 0);
 // host-side repack of a GGUF conv weight (ggml ne [K, IC, OC], f16, k fastest) into fragment order
 void   pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, int ck, uint16_t *dst);
-// all jobs of one launch share L-extent class, Cout_p and tile configuration
-hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu);
+// all jobs of one launch share the segments, Cout_p and the tile configuration; job.L is ignored (rows come from segs)
+hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
 // ---- fused HiFi-GAN dilation pair (reference src/hifigan.cpp:99-182, one loop iteration):
 //   out = y + ( conv(lrelu(conv(lrelu(y), k, dil) + b1), k, 1) + b2 )
@@ -95,13 +136,15 @@ constexpr int PAIR_MAX_JOBS = 3;
 struct PairJobs
 {
     PairJob j[PAIR_MAX_JOBS];
+    Segs    segs;
+    int     rate;
 };
 // true when a ResBlock with Cp (padded) channels can run on the fused kernel
 bool       pair_supported(int Cp);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu);
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
 // ---- a whole HiFi-GAN residual block (reference src/hifigan.cpp:74-185: the loop over all dilations) in ONE launch:
 // a workgroup keeps a 256-row f32 tile of y in LDS, runs the n_dil fused pairs on it and writes the centre rows once.
@@ -122,10 +165,12 @@ struct TripleJob
 struct TripleJobs
 {
     TripleJob j[PAIR_MAX_JOBS];
+    Segs      segs;
+    int       rate;
 };
 // true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
 bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu);
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
 struct OutConvArgs
@@ -136,38 +181,50 @@ struct OutConvArgs
     const uint16_t *w;           // f16 [K][Cp]
     float        bias;
     float       *out;            // wav[L]
+    Segs         segs;
+    int          rate;
 };
 hipError_t launch_out_conv(hipStream_t s, const OutConvArgs &a);
 
-// ---- InstanceNorm statistics over time (ggml_norm semantics, ggml-cpu.c:6880-6929) ----------------
-// stat[c] = (mean, 1/sqrtf(var + eps)); sums accumulated in f64
-hipError_t launch_in_stats(hipStream_t s, const float *x, int ld, int L, int C, float eps, float *stat);
-// y[t][c] = ((x - mean) * rstd) * g[c] + b[c]
-hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int L, int C, const float *stat,
-                             const float *g, const float *b, float *y, int ldy);
+// ---- InstanceNorm statistics over time (ggml_norm, ggml-cpu.c:6880-6929: mean and biased variance in f64, --------
+// scale = 1/sqrtf(var + eps)).  Two steps: per (segment, 32-row block, channel) partial sums (sum, sum of squares, both
+// f64; written by the producing conv's epilogue, by launch_stats_partial for tensors that no conv of ours produced,
+// or by launch_norm_apply for its own output), then launch_stats_finalize adds the blocks of a segment in block order
+// and stores (mean, rstd).  The 32-row blocks do not depend on any tile shape, so neither do the statistics.
+//   part[((u * nblk) + blk) * C + c] = double2(sum, sumsq);  nblk >= ceil(max_rows * rate / 32)
+//   stat[u * stat_seg + 2 * (c_off + c) + {0, 1}] = mean, rstd
+hipError_t launch_stats_partial(hipStream_t s, const float *x, int ldx, int C, double *part, int nblk, const Segs &segs, int rate);
+hipError_t launch_stats_finalize(hipStream_t s, const double *part, int nblk, int C, float eps, float *stat, int stat_seg,
+                                 int c_off, const Segs &segs, int rate);
+// y[t][c] = ((x - mean) * rstd) * g[c] + b[c]; `part` (may be null) receives the partial sums of y
+hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, const float *stat, int stat_seg, const float *g,
+                             const float *b, float *y, int ldy, double *part, int nblk, const Segs &segs);
 
 // ---- f32 linear layers: y[n][o] = dot(W[o][:], x[n][:]) + b[o] (ggml_mul_mat on f32 weights) --------
 // `extra` (may be null) is a second per-output addend applied after the bias: (acc + b[o]) + extra[o]
 // (AdaIN: gamma = h[:C] + 1, reference src/stylettsdec.cpp:186-189)
-hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int n, int in, const float *W, const float *b,
-                         int out, float *y, int ldy, const float *extra);
+hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int in, const float *W, const float *b, int out, float *y,
+                         int ldy, const float *extra, const Segs &segs);
 
 // ---- encoder pieces (reference src/fs2encoder.cpp) -------------------------------------------------
 hipError_t launch_embed(hipStream_t s, const int32_t *ids, const int32_t *puncts, const float *wemb, int emb,
-                        const float *pemb, int pdim, const float *posenc, int n, float *x, int ld);
-hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const float *v, int ld, int n, int H,
-                            int dk, float inv_temp, float *o, int ldo);
+                        const float *pemb, int pdim, const float *posenc, float *x, int ld, const Segs &segs);
+// softmax(q k^T * inv_temp) v per (segment, head); q, k, v [rows][ld] token-major, heads side by side
+hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const float *v, int ld, int H, int dk,
+                            float inv_temp, float *o, int ldo, const Segs &segs);
 // y = LayerNorm(x + res) * w + b  over the C real channels (res may be null); channels [C, Cp) are zeroed
-hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int n, int C,
-                                int Cp, const float *w, const float *b, float eps, float *y, int ldy);
-hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int n, int C, const float *v);
+hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp,
+                                const float *w, const float *b, float eps, float *y, int ldy, const Segs &segs);
+// x[row][:] += v[segment][:]
+hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int C, const float *v, int v_seg, const Segs &segs);
 // pred[n] = dot(x[n][:], w) + b
-hipError_t launch_rowdot(hipStream_t s, const float *x, int ld, int n, int C, const float *w, const float *b, float *y);
+hipError_t launch_rowdot(hipStream_t s, const float *x, int ld, int C, const float *w, const float *b, float *y, const Segs &segs);
 // bucket[n] = clamp((int)(pred*(nbins-1) + 0.5), 0, nbins-1); x[n][:] += emb[bucket[n]][:]
-hipError_t launch_bucket_embed_add(hipStream_t s, const float *pred, int n, int nbins, const float *emb, int C,
-                                   float *x, int ld, int32_t *bucket);
-// device length regulator: rounded durations -> exclusive scan -> gather, zero tail; n_frames[0] = frames
-hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int n, int C,
-                                   int T, float *hidden, int ldh, int32_t *n_frames);
+hipError_t launch_bucket_embed_add(hipStream_t s, const float *pred, int nbins, const float *emb, int C, float *x, int ld,
+                                   int32_t *bucket, const Segs &segs);
+// device length regulator: rounded durations of the first `aux` tokens of a segment -> inclusive scan (cum[], one int
+// per token row) -> gather into the segment's frames, zero tail; n_frames[segment] = frames
+hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int C, float *hidden,
+                                   int ldh, int32_t *cum, int32_t *n_frames, const Segs &tokens, const Segs &frames);
 
 }  // namespace zv

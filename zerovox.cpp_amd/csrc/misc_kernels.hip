@@ -1,7 +1,7 @@
 // misc_kernels.hip — the non-conv kernels of the fixed schedule: InstanceNorm statistics, f32 linear
 // layers, attention, LayerNorm, variance-adaptor bucketing and the device length regulator.
-// All of them are latency/bandwidth-trivial next to the convs (convs are > 90 % of the
-// reference's time); they exist so that no stage ever goes back to the host between kernels.
+// Every kernel maps a workgroup to (segment, tile inside the segment) — see `Segs` in kernels.h — so one launch
+// covers all utterances of a batch while each utterance keeps its own extents.
 #include "kernels.h"
 
 namespace zv
@@ -19,116 +19,196 @@ __device__ __forceinline__ float wave_sum_f(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+
+typedef float floatx16m __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
-// InstanceNorm1d statistics over time (ggml_norm: mean and biased variance of (x - mean) accumulated in f64,
-// scale = 1/sqrtf(var + eps); reference ggml-cpu.c:6906-6923).  1024 threads = 16 channels (64-B row segments)
-// x 64 time lanes: the kernel is pure latency (a few MB), so it is cut into many short strided loops.
-__global__ __launch_bounds__(1024) void in_stats_kernel(const float *__restrict__ x, int ld, int L, int C, float eps,
-                                                        float *__restrict__ stat)
+// InstanceNorm1d statistics over time (ggml_norm: mean and biased variance accumulated in f64, scale =
+// 1/sqrtf(var + eps); reference ggml-cpu.c:6906-6923), in two steps so that no kernel ever has to walk a whole
+// sequence: (1) per 32-row block and channel the f64 pair (sum x, sum x^2) — written by the conv epilogue that
+// produced the tensor (conv1d_mfma.hip: tile_stats_store), by stats_partial_kernel below for tensors that come from
+// elsewhere, or by norm_apply_kernel for its own output; (2) stats_finalize_kernel adds a segment's blocks in block
+// order.  The reference subtracts the f32 mean before squaring (two passes); sum x^2 - (sum x)^2 / L in f64 is the
+// same quantity to ~1e-12 relative, far inside the f32 rounding of the reference's own terms.
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float *__restrict__ x, int ldx, int C,
+                                                            double *__restrict__ part, int nblk, const Segs segs, int rate)
 {
-    __shared__ double red[64][17];
-    __shared__ float meanv[16];
-    const int cl = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    const bool ok = c < C;
-    double s = 0.0;
-    if (ok)
-        for (int t = ty; t < L; t += 64) s += (double)x[(size_t)t * ld + c];
-    red[ty][cl] = s;
-    __syncthreads();
-    if (ty == 0)
-    {
-        double tot = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < 64; i++) tot += red[i][cl];
-        meanv[cl] = (float)(tot / (double)L);
-    }
-    __syncthreads();
-    const float mean = meanv[cl];
-    double s2 = 0.0;
-    if (ok)
-        for (int t = ty; t < L; t += 64)
+    __shared__ double red[2][4][64];
+    const int useg = blockIdx.z, blk = blockIdx.y;
+    const Seg sg = seg_at(segs, useg);
+    const int L = sg.rows * rate;
+    if (blk * 32 >= L) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float *xs = x + (size_t)sg.row0 * rate * ldx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
         {
-            const float v = x[(size_t)t * ld + c] - mean;
-            s2 += (double)(v * v);
+            const int t = blk * 32 + rg * 8 + i;
+            const double v = (t < L) ? (double)xs[(size_t)t * ldx + c] : 0.0;
+            s1 += v;
+            s2 += v * v;
         }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
     __syncthreads();
-    red[ty][cl] = s2;
-    __syncthreads();
-    if (ty == 0 && ok)
+    if (rg == 0 && c < C)
     {
-        double tot = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < 64; i++) tot += red[i][cl];
-        const float var = (float)(tot / (double)L);
-        stat[2 * c] = mean;
-        stat[2 * c + 1] = 1.0f / sqrtf(var + eps);
+        const double a = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        const double b = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        *(double2 *)(part + (((size_t)useg * nblk + blk) * C + c) * 2) = make_double2(a, b);
     }
 }
 
-hipError_t launch_in_stats(hipStream_t s, const float *x, int ld, int L, int C, float eps, float *stat)
+hipError_t launch_stats_partial(hipStream_t s, const float *x, int ldx, int C, double *part, int nblk, const Segs &segs, int rate)
 {
-    hipLaunchKernelGGL(in_stats_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, x, ld, L, C, eps, stat);
+    const int nb = (segs.max_rows * rate + 31) / 32;
+    if (nb > nblk || segs.nseg < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stats_partial_kernel, dim3((C + 63) / 64, nb, segs.nseg), dim3(256), 0, s, x, ldx, C, part, nblk, segs, rate);
     return hipGetLastError();
 }
 
-__global__ void norm_apply_kernel(const float *__restrict__ x, int ldx, int L, int C, const float *__restrict__ stat,
-                                  const float *__restrict__ g, const float *__restrict__ b, float *__restrict__ y, int ldy)
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const double *__restrict__ part, int nblk, int C, float eps,
+                                                            float *__restrict__ stat, int stat_seg, int c_off,
+                                                            const Segs segs, int rate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = blockIdx.y;
-    if (c >= C) return;
-    float v = (x[(size_t)t * ldx + c] - stat[2 * c]) * stat[2 * c + 1];
-    v = v * g[c];
-    v = v + b[c];
-    y[(size_t)t * ldy + c] = v;
+    const int useg = blockIdx.y;
+    const Seg sg = seg_at(segs, useg);
+    const int L = sg.rows * rate;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C || L <= 0) return;
+    const int nb = (L + 31) >> 5;
+    const double *p = part + ((size_t)useg * nblk * C + c) * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; b++)
+    {
+        const double2 v = *(const double2 *)(p + (size_t)b * C * 2);
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const double mean = s1 / (double)L;
+    double var = s2 / (double)L - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    float *o = stat + (size_t)useg * stat_seg + 2 * (c_off + c);
+    o[0] = (float)mean;
+    o[1] = 1.0f / sqrtf((float)var + eps);
 }
 
-hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int L, int C, const float *stat, const float *g,
-                             const float *b, float *y, int ldy)
+hipError_t launch_stats_finalize(hipStream_t s, const double *part, int nblk, int C, float eps, float *stat, int stat_seg,
+                                 int c_off, const Segs &segs, int rate)
 {
-    hipLaunchKernelGGL(norm_apply_kernel, dim3((C + 63) / 64, L), dim3(64), 0, s, x, ldx, L, C, stat, g, b, y, ldy);
+    if (segs.nseg < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((C + 63) / 64, segs.nseg), dim3(64), 0, s, part, nblk, C, eps, stat, stat_seg,
+                       c_off, segs, rate);
+    return hipGetLastError();
+}
+
+// y = ((x - mean) * rstd) * g + b  (affine InstanceNorm written out: the decoder's asr_res branch, reference
+// src/stylettsdec.cpp:382-404) + the partial sums of y for the InstanceNorm that follows
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict__ x, int ldx, int C,
+                                                         const float *__restrict__ stat, int stat_seg,
+                                                         const float *__restrict__ g, const float *__restrict__ b,
+                                                         float *__restrict__ y, int ldy, double *__restrict__ part, int nblk,
+                                                         const Segs segs)
+{
+    __shared__ double red[2][4][64];
+    const int useg = blockIdx.z, blk = blockIdx.y;
+    const Seg sg = seg_at(segs, useg);
+    const int L = sg.rows;
+    if (blk * 32 >= L) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float *xs = x + (size_t)sg.row0 * ldx;
+    float *ys = y + (size_t)sg.row0 * ldy;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+    {
+        const float mean = stat[(size_t)useg * stat_seg + 2 * c], rstd = stat[(size_t)useg * stat_seg + 2 * c + 1];
+        const float gc = g[c], bc = b[c];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const int t = blk * 32 + rg * 8 + i;
+            if (t < L)
+            {
+                float v = (xs[(size_t)t * ldx + c] - mean) * rstd;
+                v = v * gc;
+                v = v + bc;
+                ys[(size_t)t * ldy + c] = v;
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+        }
+    }
+    if (!part) return;
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C)
+    {
+        const double a = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        const double q = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        *(double2 *)(part + (((size_t)useg * nblk + blk) * C + c) * 2) = make_double2(a, q);
+    }
+}
+
+hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, const float *stat, int stat_seg, const float *g,
+                             const float *b, float *y, int ldy, double *part, int nblk, const Segs &segs)
+{
+    const int nb = (segs.max_rows + 31) / 32;
+    if ((part && nb > nblk) || segs.nseg < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3((C + 63) / 64, nb, segs.nseg), dim3(256), 0, s, x, ldx, C, stat, stat_seg, g, b, y,
+                       ldy, part, nblk, segs);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // y[n][o] = dot(W[o][:], x[n][:]) + b[o]   (f32 weights: ggml_mul_mat + ggml_add, reference
 // src/fs2encoder.cpp:77-89,127-128 and src/stylettsdec.cpp:178-179) on the f32-input matrix cores:
-// v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (exact f32, the reference's own FMA accumulation),
-// one wave per 32 rows x 32 outputs.  Lane l holds A[row l&31][k + (l>>5)] / B[k + (l>>5)][col l&31].
+// v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (exact f32, the reference's own FMA accumulation).
+// A workgroup of 4 waves owns 64 rows x 128 outputs: wave w the outputs [32w, 32w + 32) of both 32-row halves, so a
+// W operand feeds two MFMAs.  Lane l holds A[row l&31][k + (l>>5)] / B[k + (l>>5)][col l&31].
 // `extra[o]` is added after the bias (AdaIN: gamma = h[:C] + 1, src/stylettsdec.cpp:186-189).
-typedef float floatx16m __attribute__((ext_vector_type(16)));
-
-__global__ __launch_bounds__(64) void linear_mfma_kernel(const float *__restrict__ x, int ldx, int n, int in,
-                                                         const float *__restrict__ W, const float *__restrict__ b, int out,
-                                                         float *__restrict__ y, int ldy, const float *__restrict__ extra)
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restrict__ x, int ldx, int in,
+                                                          const float *__restrict__ W, const float *__restrict__ b, int out,
+                                                          float *__restrict__ y, int ldy, const float *__restrict__ extra,
+                                                          const Segs segs, int tps)
 {
-    // 32 x 32 k-chunks of both operands go through LDS: global rows are read as coalesced 128-B segments, the MFMA
+    // 32-wide k-chunks of both operands go through LDS: global rows are read as coalesced 128-B segments, the MFMA
     // operand (one f32 per lane, rows across lanes) comes back from LDS with a 33-float row stride (conflict-free)
-    __shared__ float Xs[32][33];
-    __shared__ float Ws[32][33];
-    const int lane = threadIdx.x;
-    const int o0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    __shared__ float Xs[64][33];
+    __shared__ float Ws[128][33];
+    const int useg = blockIdx.y / tps;
+    const Seg sg = seg_at(segs, useg);
+    const int n = sg.rows;
+    const int n0 = (blockIdx.y - useg * tps) * 64;
+    if (n0 >= n) return;
+    const float *xs = x + (size_t)sg.row0 * ldx;
+    float *ys = y + (size_t)sg.row0 * ldy;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = blockIdx.x * 128;
     const int i = lane & 31, kk = lane >> 5;
-    floatx16m acc;
+    floatx16m acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    float4 xv[4], wv[4];
+    for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.f;
+    float4 xv[2], wv[4];
     auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+        {
+            const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
+            const bool kin = k0 + c < in;                      // `in` is a multiple of 4: a float4 is all in or all out
+            const int row = n0 + r;
+            xv[u] = (kin && row < n) ? *(const float4 *)(xs + (size_t)row * ldx + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
-            const int idx = lane + u * 64, r = idx >> 3, c = (idx & 7) * 4;
-            const bool kin = k0 + c < in;                      // `in` is a multiple of 4: a float4 is all in or all out
-            const int row = n0 + r, col = o0 + r;
-            xv[u] = (kin && row < n) ? *(const float4 *)(x + (size_t)row * ldx + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
+            const bool kin = k0 + c < in;
+            const int col = o0 + r;
             wv[u] = (kin && col < out) ? *(const float4 *)(W + (size_t)col * in + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -137,42 +217,54 @@ __global__ __launch_bounds__(64) void linear_mfma_kernel(const float *__restrict
     {
         __syncthreads();                                       // previous chunk fully consumed
 #pragma unroll
+        for (int u = 0; u < 2; u++)
+        {
+            const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
+            Xs[r][c] = xv[u].x; Xs[r][c + 1] = xv[u].y; Xs[r][c + 2] = xv[u].z; Xs[r][c + 3] = xv[u].w;
+        }
+#pragma unroll
         for (int u = 0; u < 4; u++)
         {
-            const int idx = lane + u * 64, r = idx >> 3, c = (idx & 7) * 4;
-            Xs[r][c] = xv[u].x; Xs[r][c + 1] = xv[u].y; Xs[r][c + 2] = xv[u].z; Xs[r][c + 3] = xv[u].w;
+            const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
             Ws[r][c] = wv[u].x; Ws[r][c + 1] = wv[u].y; Ws[r][c + 2] = wv[u].z; Ws[r][c + 3] = wv[u].w;
         }
         __syncthreads();
         if (k0 + 32 < in) fetch(k0 + 32);                      // next chunk's rows are in flight under this chunk's MFMAs
 #pragma unroll
         for (int k = 0; k < 32; k += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[i][k + kk], Ws[i][k + kk], acc, 0, 0, 0);
+        {
+            const float wk = Ws[wave * 32 + i][k + kk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[i][k + kk], wk, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[32 + i][k + kk], wk, acc1, 0, 0, 0);
+        }
     }
     // D: col = lane&31 (output), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (token)
-    const int col = o0 + i;
+    const int col = o0 + wave * 32 + i;
     if (col >= out) return;
     const float bias = b ? b[col] : 0.f;
     const float ex = extra ? extra[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r++)
-    {
-        const int t = n0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (t < n)
+    for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
         {
-            float v = acc[r] + bias;
-            if (extra) v = v + ex;
-            y[(size_t)t * ldy + col] = v;
+            const int t = n0 + hf * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (t < n)
+            {
+                float v = (hf ? acc1[r] : acc0[r]) + bias;
+                if (extra) v = v + ex;
+                ys[(size_t)t * ldy + col] = v;
+            }
         }
-    }
 }
 
-hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int n, int in, const float *W, const float *b, int out,
-                         float *y, int ldy, const float *extra)
+hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int in, const float *W, const float *b, int out, float *y,
+                         int ldy, const float *extra, const Segs &segs)
 {
-    if ((in & 3) || (ldx & 3)) return hipErrorInvalidValue;          // float4 row loads
-    hipLaunchKernelGGL(linear_mfma_kernel, dim3((out + 31) / 32, (n + 31) / 32), dim3(64), 0, s, x, ldx, n, in, W, b, out, y,
-                       ldy, extra);
+    if ((in & 3) || (ldx & 3) || segs.nseg < 1) return hipErrorInvalidValue;          // float4 row loads
+    const int tps = (segs.max_rows + 63) / 64;
+    hipLaunchKernelGGL(linear_mfma_kernel, dim3((out + 127) / 128, tps * segs.nseg), dim3(256), 0, s, x, ldx, in, W, b, out, y, ldy,
+                       extra, segs, tps);
     return hipGetLastError();
 }
 
@@ -180,54 +272,220 @@ hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int n, int in, 
 // Encoder::graph prologue (reference src/fs2encoder.cpp:306-324): x[n] = cat(word_emb[id], punct_emb[p]) + posenc[n]
 __global__ void embed_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ puncts,
                              const float *__restrict__ wemb, int emb, const float *__restrict__ pemb, int pdim,
-                             const float *__restrict__ posenc, float *__restrict__ x, int ld)
+                             const float *__restrict__ posenc, float *__restrict__ x, int ld, const Segs segs)
 {
-    const int n = blockIdx.x;
+    const Seg sg = seg_at(segs, blockIdx.y);
+    const int n = blockIdx.x;                       // position inside the utterance
+    if (n >= sg.rows) return;
+    const size_t row = (size_t)sg.row0 + n;
     const int E = emb + pdim;
-    const int id = ids[n], p = puncts[n];
+    const int id = ids[row], p = puncts[row];
     for (int e = threadIdx.x; e < E; e += blockDim.x)
     {
         const float v = (e < emb) ? wemb[(size_t)id * emb + e] : pemb[(size_t)p * pdim + (e - emb)];
-        x[(size_t)n * ld + e] = v + posenc[(size_t)n * E + e];
+        x[row * ld + e] = v + posenc[(size_t)n * E + e];
     }
 }
 
 hipError_t launch_embed(hipStream_t s, const int32_t *ids, const int32_t *puncts, const float *wemb, int emb,
-                        const float *pemb, int pdim, const float *posenc, int n, float *x, int ld)
+                        const float *pemb, int pdim, const float *posenc, float *x, int ld, const Segs &segs)
 {
-    hipLaunchKernelGGL(embed_kernel, dim3(n), dim3(256), 0, s, ids, puncts, wemb, emb, pemb, pdim, posenc, x, ld);
+    hipLaunchKernelGGL(embed_kernel, dim3(segs.max_rows, segs.nseg), dim3(256), 0, s, ids, puncts, wemb, emb, pemb, pdim, posenc, x,
+                       ld, segs);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ScaledDotProductAttention without mask (reference src/fs2encoder.cpp:103-123): one block per (query, head).
-// scores = (q.k) * inv_temp -> softmax over keys (max-subtracted, sum in f64) -> out[d] = sum_k p[k] v[k][d].
-// q,k,v are [n][H*dk] token-major; the head-major concat of the reference is the same memory layout.
+// ScaledDotProductAttention without mask (reference src/fs2encoder.cpp:103-123) on the f32 matrix cores.
+// One workgroup (4 waves) = 64 queries of one (utterance, head):
+//   scores : wave (qt = w & 1, kh = w >> 1) computes the transposed tile S^T[32 keys][32 queries] = K_tile . Q_tile^T
+//            for its query half qt and every second key tile (K tiles staged through LDS two at a time, the wave's
+//            Q fragment lives in registers), scales by 1/temperature as a separate multiply (src/fs2encoder.cpp:107)
+//            and parks it in LDS as S[key][query];
+//   softmax: per query over all keys, max-subtracted, sum in f64, 1/sum applied as an f32 multiply (ggml soft_max);
+//   P . V  : wave (qt, dh) accumulates its share of the 32-wide d tiles over the keys in ascending order; the P operand
+//            comes straight from LDS, V rows straight from L2 (128-B segments).
+// v_mfma_f32_32x32x2_f32 is an exact k-ordered f32 fma chain, so every dot product is accumulated in index order.
+constexpr int ATT_NS_MAX = 144;          // dk <= 288
+constexpr int ATT_NDT_MAX = 5;           // d tiles per wave: dk <= 320
+constexpr int ATT_LDS_MAX = 160 * 1024 - 4096;
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                             const float *__restrict__ v, int ld, int dk, float inv_temp,
+                                                             float *__restrict__ o, int ldo, const Segs segs)
+{
+    extern __shared__ __attribute__((aligned(16))) float att_sm[];
+    __shared__ float redm[4][64];
+    __shared__ double redd[4][64];
+    const Seg sg = seg_at(segs, blockIdx.z);
+    const int n = sg.rows;
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= n) return;
+    const int h = blockIdx.y;
+    const size_t rb = (size_t)sg.row0;
+    const float *qs = q + rb * ld + h * dk, *ks = k + rb * ld + h * dk, *vs = v + rb * ld + h * dk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qt = wave & 1, kh = wave >> 1;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int ns = dk >> 1, KSTR = dk | 1;                 // odd row stride: conflict-free column reads
+    float *Ks = att_sm;                                    // [64][KSTR]
+    float *S = att_sm + 64 * KSTR + ((64 * KSTR) & 1);     // [n_pad][64]
+    const int nkt = (n + 31) >> 5;
+
+    // ---- this lane's Q fragment: B[k = 2s + hh][col = query ql]
+    float qreg[ATT_NS_MAX];
+    {
+        const int qrow = min(q0 + qt * 32 + ql, n - 1);
+        const float *qp = qs + (size_t)qrow * ld;
+#pragma unroll
+        for (int j = 0; j < ATT_NS_MAX / 2; j++)
+        {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * j < dk) t = *(const float4 *)(qp + 4 * j);
+            qreg[2 * j] = hh ? t.y : t.x;
+            qreg[2 * j + 1] = hh ? t.w : t.z;
+        }
+    }
+
+    // ---- scores
+    const int c4n = dk >> 2;
+    for (int kt0 = 0; kt0 < nkt; kt0 += 2)
+    {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * c4n; idx += 256)
+        {
+            const int r = idx / c4n, c4 = idx - r * c4n;
+            const int key = kt0 * 32 + r;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key < n) t = *(const float4 *)(ks + (size_t)key * ld + c4 * 4);
+            float *d = Ks + r * KSTR + c4 * 4;
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        }
+        __syncthreads();
+        const int kt = kt0 + kh;
+        if (kt < nkt)
+        {
+            floatx16m acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            const float *kr = Ks + (kh * 32 + ql) * KSTR + hh;
+#pragma unroll
+            for (int s = 0; s < ATT_NS_MAX; s++)
+                if (s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qreg[s], acc, 0, 0, 0);
+            // D[row = key (r&3) + 8*(r>>2) + 4*hh][col = query ql]
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key < n) S[(size_t)key * 64 + qt * 32 + ql] = acc[r] * inv_temp;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over keys: thread (query = tid & 63, part = tid >> 6) walks keys part, part + 4, ...
+    {
+        const int qi = tid & 63, part = tid >> 6;
+        float mx = -INFINITY;
+        for (int key = part; key < n; key += 4) mx = fmaxf(mx, S[(size_t)key * 64 + qi]);
+        redm[part][qi] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(redm[0][qi], redm[1][qi]), fmaxf(redm[2][qi], redm[3][qi]));
+        double sum = 0.0;
+        for (int key = part; key < n; key += 4)
+        {
+            const float e = expf(S[(size_t)key * 64 + qi] - mx);
+            S[(size_t)key * 64 + qi] = e;
+            sum += (double)e;
+        }
+        redd[part][qi] = sum;
+        __syncthreads();
+        const float inv = (float)(1.0 / ((redd[0][qi] + redd[1][qi]) + (redd[2][qi] + redd[3][qi])));
+        for (int key = part; key < n; key += 4) S[(size_t)key * 64 + qi] = S[(size_t)key * 64 + qi] * inv;
+    }
+    __syncthreads();
+
+    // ---- P . V: wave (qt, dh = kh) owns d tiles dh, dh + 2, ...
+    const int ndt = (dk + 31) >> 5;
+    floatx16m oacc[ATT_NDT_MAX];
+#pragma unroll
+    for (int i = 0; i < ATT_NDT_MAX; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[i][r] = 0.f;
+    const float *pp = S + qt * 32 + ql;
+    const int npair = (n + 1) >> 1;
+    for (int s0 = 0; s0 < npair; s0 += 4)
+    {
+        float a[4], bv[4][ATT_NDT_MAX];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int key = 2 * (s0 + u) + hh;
+            const bool kin = key < n;
+            a[u] = kin ? pp[(size_t)key * 64] : 0.f;
+            const float *vr = vs + (size_t)(kin ? key : 0) * ld + ql;
+#pragma unroll
+            for (int i = 0; i < ATT_NDT_MAX; i++)
+            {
+                const int d0 = (kh + 2 * i) * 32;
+                bv[u][i] = (kin && d0 + ql < dk) ? vr[d0] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < ATT_NDT_MAX; i++)
+                if (kh + 2 * i < ndt) oacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][i], oacc[i], 0, 0, 0);
+    }
+    // D[row = query (r&3) + 8*(r>>2) + 4*hh][col = d ql]
+    float *os = o + rb * ldo + h * dk;
+#pragma unroll
+    for (int i = 0; i < ATT_NDT_MAX; i++)
+    {
+        const int d = (kh + 2 * i) * 32 + ql;
+        if (kh + 2 * i < ndt && d < dk)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int qi = q0 + qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (qi < n) os[(size_t)qi * ldo + d] = oacc[i][r];
+            }
+    }
+}
+
+// The same operation with scalar fma chains: one block per (query, head).  Fallback for shapes outside the matrix-core
+// kernel's limits (head width not a multiple of 4 or above 288, more keys than fit its LDS score tile).
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                        const float *__restrict__ v, int ld, int n, int dk, float inv_temp,
-                                                        float *__restrict__ o, int ldo)
+                                                        const float *__restrict__ v, int ld, int dk, float inv_temp,
+                                                        float *__restrict__ o, int ldo, const Segs segs)
 {
     extern __shared__ float sm[];
+    const Seg sg = seg_at(segs, blockIdx.z);
+    const int n = sg.rows;
+    const int iq = blockIdx.x, h = blockIdx.y;
+    if (iq >= n) return;
     float *qs = sm;                 // dk
     float *p = sm + dk;             // n
     __shared__ double redd[4];
     __shared__ float redf[4];
-    const int iq = blockIdx.x, h = blockIdx.y;
+    const size_t rb = (size_t)sg.row0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float *qrow = q + (size_t)iq * ld + h * dk;
+    const float *qrow = q + (rb + iq) * ld + h * dk;
     for (int d = tid; d < dk; d += 256) qs[d] = qrow[d];
     __syncthreads();
     float mx = -INFINITY;
     for (int ik = tid; ik < n; ik += 256)
     {
-        const float *krow = k + (size_t)ik * ld + h * dk;
+        const float *krow = k + (rb + ik) * ld + h * dk;
         float acc = 0.f;
         for (int d = 0; d < dk; d++) acc = fmaf(qs[d], krow[d], acc);
         acc = acc * inv_temp;
         p[ik] = acc;
         mx = fmaxf(mx, acc);
     }
-    mx = wave_max_f(mx);
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
     if (lane == 0) redf[wv] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
@@ -246,34 +504,53 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     __syncthreads();
     for (int d = tid; d < dk; d += 256)
     {
-        const float *vcol = v + h * dk + d;
+        const float *vcol = v + rb * ld + h * dk + d;
         float acc = 0.f;
         for (int ik = 0; ik < n; ik++) acc = fmaf(p[ik], vcol[(size_t)ik * ld], acc);
-        o[(size_t)iq * ldo + h * dk + d] = acc;
+        o[(rb + iq) * ldo + h * dk + d] = acc;
     }
 }
 
-hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const float *v, int ld, int n, int H, int dk,
-                            float inv_temp, float *o, int ldo)
+hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const float *v, int ld, int H, int dk,
+                            float inv_temp, float *o, int ldo, const Segs &segs)
 {
+    if (segs.nseg < 1) return hipErrorInvalidValue;
+    const int n = segs.max_rows;
+    const int KSTR = dk | 1;
+    const size_t lds_mfma = ((size_t)64 * KSTR + 1 + (size_t)((n + 31) & ~31) * 64) * sizeof(float);
+    static const bool force_scalar = getenv("ZV_ATT_SCALAR") && atoi(getenv("ZV_ATT_SCALAR")) != 0;     // test hook
+    if (!force_scalar && (dk & 3) == 0 && dk <= 2 * ATT_NS_MAX && (ld & 3) == 0 && lds_mfma <= (size_t)ATT_LDS_MAX)
+    {
+        auto kern = attention_mfma_kernel;
+        if (lds_mfma > 48 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((n + 63) / 64, H, segs.nseg), dim3(256), lds_mfma, s, q, k, v, ld, dk, inv_temp, o, ldo, segs);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(dk + n) * sizeof(float);
-    hipLaunchKernelGGL(attention_kernel, dim3(n, H), dim3(256), lds, s, q, k, v, ld, n, dk, inv_temp, o, ldo);
+    if (lds > 60 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_kernel, dim3(n, H, segs.nseg), dim3(256), lds, s, q, k, v, ld, dk, inv_temp, o, ldo, segs);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // y = LayerNorm(x + res) * w + b over channels: one wave per row (reference src/fs2encoder.cpp:132-137,
-// ggml_norm semantics as in in_stats_kernel)
+// ggml_norm: mean and biased variance of (x - mean) accumulated in f64)
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, int ldx,
-                                                            const float *__restrict__ res, int ldr, int n, int C, int Cp,
+                                                            const float *__restrict__ res, int ldr, int C, int Cp,
                                                             const float *__restrict__ w, const float *__restrict__ b,
-                                                            float eps, float *__restrict__ y, int ldy)
+                                                            float eps, float *__restrict__ y, int ldy, const Segs segs)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const Seg sg = seg_at(segs, blockIdx.y);
+    const int rloc = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    const float *xr = x + (size_t)row * ldx;
-    const float *rr = res ? res + (size_t)row * ldr : nullptr;
+    if (rloc >= sg.rows) return;
+    const size_t row = (size_t)sg.row0 + rloc;
+    const float *xr = x + row * ldx;
+    const float *rr = res ? res + row * ldr : nullptr;
     // rows of up to 64 * LN_MAXE channels are read once and kept in registers for the three passes (same per-lane
     // summation order as the plain three-pass form below, so the same bits)
     constexpr int LN_MAXE = 12;
@@ -311,10 +588,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
             {
                 float t = (v[e] - mean) * scale;
                 t = w[c] * t;
-                y[(size_t)row * ldy + c] = t + b[c];
+                y[row * ldy + c] = t + b[c];
             }
         }
-        for (int c = C + lane; c < Cp; c += 64) y[(size_t)row * ldy + c] = 0.f;
+        for (int c = C + lane; c < Cp; c += 64) y[row * ldy + c] = 0.f;
         return;
     }
     double s = 0.0;
@@ -334,88 +611,102 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     {
         float v = ((rr ? xr[c] + rr[c] : xr[c]) - mean) * scale;
         v = w[c] * v;
-        y[(size_t)row * ldy + c] = v + b[c];
+        y[row * ldy + c] = v + b[c];
     }
-    for (int c = C + lane; c < Cp; c += 64) y[(size_t)row * ldy + c] = 0.f;
+    for (int c = C + lane; c < Cp; c += 64) y[row * ldy + c] = 0.f;
 }
 
-hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int n, int C, int Cp,
-                                const float *w, const float *b, float eps, float *y, int ldy)
+hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp,
+                                const float *w, const float *b, float eps, float *y, int ldy, const Segs &segs)
 {
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, ldx, res, ldr, n, C, Cp, w, b, eps, y, ldy);
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((segs.max_rows + 3) / 4, segs.nseg), dim3(256), 0, s, x, ldx, res, ldr, C, Cp, w, b,
+                       eps, y, ldy, segs);
     return hipGetLastError();
 }
 
-__global__ void add_rowvec_kernel(float *__restrict__ x, int ld, int C, const float *__restrict__ v)
+__global__ void add_rowvec_kernel(float *__restrict__ x, int ld, int C, const float *__restrict__ v, int v_seg, const Segs segs)
 {
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) x[(size_t)n * ld + c] = x[(size_t)n * ld + c] + v[c];
+    const Seg sg = seg_at(segs, blockIdx.y);
+    if ((int)blockIdx.x >= sg.rows) return;
+    const size_t row = (size_t)sg.row0 + blockIdx.x;
+    const float *vv = v + (size_t)blockIdx.y * v_seg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[row * ld + c] = x[row * ld + c] + vv[c];
 }
 
-hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int n, int C, const float *v)
+hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int C, const float *v, int v_seg, const Segs &segs)
 {
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3(n), dim3(256), 0, s, x, ld, C, v);
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(segs.max_rows, segs.nseg), dim3(256), 0, s, x, ld, C, v, v_seg, segs);
     return hipGetLastError();
 }
 
 // VariancePredictor linear_layer (reference src/fs2encoder.cpp:434-435): one wave per token
-__global__ __launch_bounds__(256) void rowdot_kernel(const float *__restrict__ x, int ld, int n, int C,
-                                                     const float *__restrict__ w, const float *__restrict__ b,
-                                                     float *__restrict__ y)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float *__restrict__ x, int ld, int C, const float *__restrict__ w,
+                                                     const float *__restrict__ b, float *__restrict__ y, const Segs segs)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const Seg sg = seg_at(segs, blockIdx.y);
+    const int rloc = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (rloc >= sg.rows) return;
+    const size_t row = (size_t)sg.row0 + rloc;
     float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(x[(size_t)row * ld + c], w[c], acc);
+    for (int c = lane; c < C; c += 64) acc = fmaf(x[row * ld + c], w[c], acc);
     acc = wave_sum_f(acc);
     if (lane == 0) y[row] = acc + b[0];
 }
 
-hipError_t launch_rowdot(hipStream_t s, const float *x, int ld, int n, int C, const float *w, const float *b, float *y)
+hipError_t launch_rowdot(hipStream_t s, const float *x, int ld, int C, const float *w, const float *b, float *y, const Segs &segs)
 {
-    hipLaunchKernelGGL(rowdot_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, ld, n, C, w, b, y);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((segs.max_rows + 3) / 4, segs.nseg), dim3(256), 0, s, x, ld, C, w, b, y, segs);
     return hipGetLastError();
 }
 
 // ggml_zv_mul_clamp_to_i32 + get_rows + add (reference src/fs2encoder.cpp:442-474,565-569)
 __global__ void bucket_embed_add_kernel(const float *__restrict__ pred, int nbins, const float *__restrict__ emb, int C,
-                                        float *__restrict__ x, int ld, int32_t *__restrict__ bucket)
+                                        float *__restrict__ x, int ld, int32_t *__restrict__ bucket, const Segs segs)
 {
-    const int n = blockIdx.x;
+    const Seg sg = seg_at(segs, blockIdx.y);
+    if ((int)blockIdx.x >= sg.rows) return;
+    const size_t n = (size_t)sg.row0 + blockIdx.x;
     const int bin_max = nbins - 1;
     float p = pred[n];
     p = p * (float)bin_max;
     int y = (int)((double)p + 0.5);          // truncating cast of x + 0.5 (double), not round-half-even
     y = y < 0 ? 0 : (y > bin_max ? bin_max : y);
     if (threadIdx.x == 0) bucket[n] = y;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) x[(size_t)n * ld + c] = x[(size_t)n * ld + c] + emb[(size_t)y * C + c];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[n * ld + c] = x[n * ld + c] + emb[(size_t)y * C + c];
 }
 
-hipError_t launch_bucket_embed_add(hipStream_t s, const float *pred, int n, int nbins, const float *emb, int C, float *x,
-                                   int ld, int32_t *bucket)
+hipError_t launch_bucket_embed_add(hipStream_t s, const float *pred, int nbins, const float *emb, int C, float *x, int ld,
+                                   int32_t *bucket, const Segs &segs)
 {
-    hipLaunchKernelGGL(bucket_embed_add_kernel, dim3(n), dim3(256), 0, s, pred, nbins, emb, C, x, ld, bucket);
+    hipLaunchKernelGGL(bucket_embed_add_kernel, dim3(segs.max_rows, segs.nseg), dim3(256), 0, s, pred, nbins, emb, C, x, ld, bucket,
+                       segs);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Length regulator on the device (the reference does it on the host, src/fs2encoder.cpp:611-654):
-//   dur_i = (int)((float)(exp(logdur_i) - 1.0) + 0.5);  frame f belongs to the token whose cumulative
-//   duration first exceeds f; frames past the total (or past T) are zero.
-__global__ __launch_bounds__(1024) void lr_scan_kernel(const float *__restrict__ logdur, int n, int T,
-                                                       int32_t *__restrict__ cum, int32_t *__restrict__ n_frames)
+//   dur_i = (int)((float)(exp(logdur_i) - 1.0) + 0.5) for the first num_phonemes (= aux) tokens of the utterance;
+//   frame f belongs to the token whose cumulative duration first exceeds f; frames past the total (or past T) are zero.
+__global__ __launch_bounds__(1024) void lr_scan_kernel(const float *__restrict__ logdur, int32_t *__restrict__ cum,
+                                                       int32_t *__restrict__ n_frames, const Segs tokens, const Segs frames)
 {
     __shared__ int buf[1024];
+    const Seg tk = seg_at(tokens, blockIdx.x), fr = seg_at(frames, blockIdx.x);
+    const int n = tk.rows, T = fr.rows;
+    if (n <= 0) return;
+    const int nwalk = tk.aux < n ? tk.aux : n;
+    const float *ld_ = logdur + tk.row0;
+    int32_t *cm = cum + tk.row0;
     const int tid = threadIdx.x;
     int carry = 0;
     for (int base = 0; base < n; base += 1024)
     {
         const int i = base + tid;
         int d = 0;
-        if (i < n)
+        if (i < nwalk)
         {
-            const float dur = (float)(exp((double)logdur[i]) - 1.0);
+            const float dur = (float)(exp((double)ld_[i]) - 1.0);
             d = (int)((double)dur + 0.5);
             if (d < 0) d = 0;
             if (d > T) d = T;          // keeps the running sum far from int overflow; frames stop at T anyway
@@ -429,36 +720,41 @@ __global__ __launch_bounds__(1024) void lr_scan_kernel(const float *__restrict__
             buf[tid] += v;
             __syncthreads();
         }
-        if (i < n) cum[i] = carry + buf[tid];
+        if (i < n) cm[i] = carry + buf[tid];
         carry += buf[1023];
         __syncthreads();
     }
-    if (tid == 0) n_frames[0] = carry < T ? carry : T;
+    if (tid == 0) n_frames[blockIdx.x] = carry < T ? carry : T;
 }
 
-__global__ void lr_gather_kernel(const float *__restrict__ feat, int ld, const int32_t *__restrict__ cum, int n, int C,
-                                 float *__restrict__ hidden, int ldh)
+__global__ void lr_gather_kernel(const float *__restrict__ feat, int ld, const int32_t *__restrict__ cum, int C,
+                                 float *__restrict__ hidden, int ldh, const Segs tokens, const Segs frames)
 {
+    const Seg tk = seg_at(tokens, blockIdx.y), fr = seg_at(frames, blockIdx.y);
     const int f = blockIdx.x;
+    if (f >= fr.rows) return;
+    const int n = tk.rows;
+    const int32_t *cm = cum + tk.row0;
     // first token i with cum[i] > f
     int lo = 0, hi = n;
     while (lo < hi)
     {
         const int mid = (lo + hi) >> 1;
-        if (cum[mid] > f) hi = mid; else lo = mid + 1;
+        if (cm[mid] > f) hi = mid; else lo = mid + 1;
     }
     const bool live = lo < n;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-        hidden[(size_t)f * ldh + c] = live ? feat[(size_t)lo * ld + c] : 0.f;
+    const float *src = feat + ((size_t)tk.row0 + lo) * ld;
+    float *dst = hidden + ((size_t)fr.row0 + f) * ldh;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = live ? src[c] : 0.f;
 }
 
-hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int n, int C, int T,
-                                   float *hidden, int ldh, int32_t *n_frames)
+hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int C, float *hidden,
+                                   int ldh, int32_t *cum, int32_t *n_frames, const Segs &tokens, const Segs &frames)
 {
-    // cum[] lives right behind n_frames (caller reserves 1 + n ints)
-    int32_t *cum = n_frames + 1;
-    hipLaunchKernelGGL(lr_scan_kernel, dim3(1), dim3(1024), 0, s, logdur, n, T, cum, n_frames);
-    hipLaunchKernelGGL(lr_gather_kernel, dim3(T), dim3(256), 0, s, feat, ld, cum, n, C, hidden, ldh);
+    if (tokens.nseg != frames.nseg || tokens.nseg < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lr_scan_kernel, dim3(tokens.nseg), dim3(1024), 0, s, logdur, cum, n_frames, tokens, frames);
+    hipLaunchKernelGGL(lr_gather_kernel, dim3(frames.max_rows, frames.nseg), dim3(256), 0, s, feat, ld, cum, C, hidden, ldh, tokens,
+                       frames);
     return hipGetLastError();
 }
 

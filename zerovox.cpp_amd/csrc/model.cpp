@@ -217,6 +217,8 @@ Model::Model(const std::string &path, int dev) : device(dev)
         hp.voc_upsample_scales[i] = s;
         hop *= s;
         voc_.ups[i] = load_upsample(g, i, s, C);
+        // the schedule's buffers are sized for channel halving per stage (every HiFi-GAN generator; 512 -> 32 here)
+        if ((int)g.get(nm).ne[2] * 2 != C) fail(ZV_ERR_SHAPE, "tensor %s: %lld output channels, expected %d (channels halve per upsample stage)", nm, (long long)g.get(nm).ne[2], C / 2);
         C = (int)g.get(nm).ne[2];
         for (int j = 0; j < voc_.n_rb; j++)
             for (int d = 0; d < voc_.n_dil; d++)
@@ -252,6 +254,8 @@ Model::Model(const std::string &path, int dev) : device(dev)
         const GgufTensor &w = g.get("_meldec.output_conv.1.w");
         const GgufTensor &b = g.get("_meldec.output_conv.1.b");
         if (w.type != GGML_F16 || w.ne[1] != C || w.ne[2] != 1) fail(ZV_ERR_SHAPE, "_meldec.output_conv.1.w: expected f16 [K,%d,1]", C);
+        if (b.type != GGML_F32 || b.nelements() != 1) fail(ZV_ERR_SHAPE, "_meldec.output_conv.1.b: expected f32 [1]");
+        if ((hp.voc_channels >> n_up) != (uint32_t)C) fail(ZV_ERR_SHAPE, "vocoder channels %u do not halve down to %d over %d stages", hp.voc_channels, C, n_up);
         voc_.out_K = (int)w.ne[0];
         voc_.out_C = C;
         const int Cp = round_up(C, 16);
@@ -354,10 +358,13 @@ Model::Model(const std::string &path, int dev) : device(dev)
         const GgufTensor &pe = g.get("_pe._enc.punct_embed.w");
         const GgufTensor &st = g.get("sinusoid_encoding_table");
         if (we.ne[0] != hp.emb_dim || pe.ne[0] != hp.punct_emb_dim || st.ne[0] != Ed) fail(ZV_ERR_SHAPE, "embedding / position tables do not match emb_dim/punct_emb_dim");
+        if (we.ne[1] < 1 || pe.ne[1] < 1 || st.ne[1] < 1) fail(ZV_ERR_SHAPE, "empty embedding / position table");
         enc_.wemb = upload_f32(we);
         enc_.pemb = upload_f32(pe);
         enc_.posenc = upload_f32(st);
         enc_.posenc_rows = (int)st.ne[1];
+        enc_.wemb_rows = (int)we.ne[1];          // ids are checked against what the file holds (155 / 7 rows in the
+        enc_.pemb_rows = (int)pe.ne[1];          // reference's checkpoints, src/zerovox.h:35-36)
         enc_.layers.resize(hp.encoder_layer);
         for (uint32_t l = 0; l < hp.encoder_layer; l++)
         {
@@ -527,11 +534,28 @@ void *Model::io_scratch(size_t bytes)
 // ---------------------------------------------------------------------------------------------------
 // activation arena
 
-size_t Model::arena_bytes_for(uint32_t N, uint32_t T) const
+uint32_t Model::max_frames_per_utterance() const
 {
-    const size_t Ed = E();
+    // buffer descriptors address a segment with 32-bit byte offsets: rows * channels * 4 < 2^31 at every stage
+    // (rows * channels peaks at the first upsample stages: T * hop * C_last <= T * s0 * C0 / 2 ...)
+    uint64_t worst = (uint64_t)round_up(hp.voc_channels, 16);
+    uint64_t rate = 1, C = hp.voc_channels;
+    for (uint32_t i = 0; i < hp.voc_num_upsamples; i++)
+    {
+        rate *= hp.voc_upsample_scales[i];
+        C >>= 1;
+        worst = std::max<uint64_t>(worst, rate * (uint64_t)round_up((int)C, 16));
+    }
+    worst = std::max<uint64_t>(worst, (uint64_t)(2 * E() + dec_.R));
+    const uint64_t lim = ((uint64_t)1 << 31) / (4 * worst) - 64;
+    return (uint32_t)std::min<uint64_t>(lim, 32768);
+}
+
+size_t Model::arena_bytes_for(size_t n_rows, size_t t_rows, int nseg) const
+{
+    const size_t Ed = E(), N = n_rows, T = t_rows, S = (size_t)nseg;
     // vocoder: c0 + two ping-pong pools of (up + 3 y + 3 xt) sized for the widest stages
-    size_t voc = (size_t)T * round_up(hp.voc_channels, 16) * 4;
+    size_t voc = T * round_up(hp.voc_channels, 16) * 4;
     size_t pool[2] = {0, 0};
     size_t L = T;
     int C = hp.voc_channels;
@@ -544,12 +568,15 @@ size_t Model::arena_bytes_for(uint32_t N, uint32_t T) const
         pool[i & 1] = std::max(pool[i & 1], need);
     }
     voc += pool[0] + pool[1] + 4096;
-    // decoder: cat + a handful of [T][2E] buffers
+    // decoder: cat + a handful of [T][2E] buffers + per-segment vectors + three sets of statistics partials
     const size_t CAT = 2 * Ed + dec_.R;
-    size_t dec = (size_t)T * (CAT + 4 * 2 * Ed + 2 * dec_.R) * 4 + (size_t)(dec_.fc_out + 4 * CAT) * 4 * 2 + 65536;
+    const size_t nblk = T / 32 + S;           // >= sum over segments of ceil(T_u / 32) ... sized per segment below
+    (void)nblk;
+    size_t dec = T * (CAT + 4 * 2 * Ed + 2 * dec_.R) * 4 + S * (size_t)(dec_.fc_out + 8 * CAT + 512) * 4 +
+                 3 * (T / 32 + S) * CAT * 16 + 65536;
     // encoder
     const size_t Fp = round_up(hp.conv_filter_size, 16);
-    size_t enc = (size_t)N * (Ed * 8 + 3 * Ed + Fp + 1024) * 4 + (size_t)T * Ed * 4 + 65536;
+    size_t enc = N * (Ed * 8 + 3 * Ed + Fp + 1024) * 4 + 65536;
     return std::max(voc, std::max(dec, enc)) + (1 << 20);
 }
 
@@ -573,8 +600,10 @@ void Model::arena_require(size_t bytes)
 
 void Model::reserve(uint32_t max_phonemes, uint32_t max_frames)
 {
-    arena_require(arena_bytes_for(std::max(1u, max_phonemes), std::max(1u, max_frames)));
+    arena_require(arena_bytes_for(std::max(1u, max_phonemes), std::max(1u, max_frames), 1));
 }
+
+void Model::reserve_batch(const Batch &b) { arena_require(arena_bytes_for(b.n_rows, b.t_rows, b.nseg)); }
 
 // ---------------------------------------------------------------------------------------------------
 // launch helpers
@@ -642,11 +671,10 @@ void Model::group_end(const char *name)
         tock(_e0, name, bytes, flops);               \
     } while (0)
 
-ConvJob Model::job(const ConvW &w, int L) const
+ConvJob Model::job(const ConvW &w) const
 {
     ConvJob j;
     memset(&j, 0, sizeof(j));
-    j.L = L;
     j.Cin_p = w.Cin_p;
     j.Cout_p = w.Cout_p;
     j.K = w.K;
@@ -664,48 +692,51 @@ ConvJob Model::job(const ConvW &w, int L) const
     return j;
 }
 
-void Model::conv(const ConvJob *jobs, int n, const char *name, double bytes, double flops)
+void Model::conv(const ConvJob *jobs, int n, const Segs &segs, int rate, const char *name, double bytes, double flops)
 {
-    ZV_LAUNCH(name, bytes, flops, launch_conv(stream, jobs, n, n_cu));
+    ZV_LAUNCH(name, bytes, flops, launch_conv(stream, jobs, n, n_cu, segs, rate));
 }
 
 // algorithmic bytes / flops of one conv layer: f32 activations in + out (+ residual),
-// f16 weights, f32 bias; 2*L*Cin*Cout*K flops
-static double conv_bytes(int L, int Cin, int Cout, int K, bool res)
+// f16 weights, f32 bias; 2*L*Cin*Cout*K flops.  L = the batch's capacity rows (exact for a single utterance and for
+// batches of equal-length utterances).
+static double conv_bytes(double L, int Cin, int Cout, int K, bool res)
 {
     return 4.0 * L * Cin + 4.0 * L * Cout + (res ? 4.0 * L * Cout : 0.0) + 2.0 * Cin * Cout * K + 4.0 * Cout;
 }
-static double conv_flops(int L, int Cin, int Cout, int K) { return 2.0 * L * Cin * Cout * K; }
+static double conv_flops(double L, int Cin, int Cout, int K) { return 2.0 * L * Cin * Cout * K; }
 
 // ---------------------------------------------------------------------------------------------------
 // HiFi-GAN vocoder (reference src/hifigan.cpp:187-377): fixed schedule of 2 + n_up * 7 launches
 
-void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
+void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
 {
-    if (T == 0) fail(ZV_ERR_ARG, "T must be > 0");
-    arena_require(arena_bytes_for(1, T));
+    if (bt.t_rows == 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "T must be > 0");
+    arena_require(arena_bytes_for(1, bt.t_rows, bt.nseg));
     arena_.used = 0;
+    const Segs fr = bt.frames();
     const int M = hp.audio_num_mels;
-    int L = (int)T;
+    size_t L = bt.t_rows;                       // capacity rows at the current stage
+    int rate = 1;
     int C = voc_.in_conv.Cout;
-    float *c0 = arena_.take_n<float>((size_t)L * voc_.in_conv.Cout_p);
+    float *c0 = arena_.take_n<float>(L * voc_.in_conv.Cout_p);
 
     // V0: (mel - mean) / scale -> input conv k7 + bias            (src/hifigan.cpp:242-265)
     {
-        ConvJob j = job(voc_.in_conv, L);
+        ConvJob j = job(voc_.in_conv);
         j.x0 = d_mel;
         j.ldx = M;
         j.pro = PRO_MELNORM;
         j.pa = voc_.mean;
         j.pb = voc_.scale;
         j.out = c0;
-        conv(&j, 1, "voc_input_conv", conv_bytes(L, M, C, j.K, false), conv_flops(L, M, C, j.K));
+        conv(&j, 1, fr, rate, "voc_input_conv", conv_bytes((double)L, M, C, j.K, false), conv_flops((double)L, M, C, j.K));
     }
 
     char *pool_base[2];
     size_t pool_sz[2] = {0, 0};
     {
-        size_t Ls = T;
+        size_t Ls = bt.t_rows;
         int Cs = C;
         for (int i = 0; i < voc_.n_up; i++)
         {
@@ -725,29 +756,31 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         const int s = voc_.scales[i];
         const ConvW &up = voc_.ups[i];
         const int Cout = C >> 1, Cp = round_up(Cout, 16);
-        const int Lo = L * s;
+        const size_t Lo = L * s;
         DeviceArena pool;
         pool.base = pool_base[i & 1];
         pool.cap = pool_sz[i & 1];
-        float *ub = pool.take_n<float>((size_t)Lo * Cp);
+        float *ub = pool.take_n<float>(Lo * Cp);
         float *y[3];
         _Float16 *xt[3];
-        for (int j = 0; j < 3; j++) y[j] = pool.take_n<float>((size_t)Lo * Cp);
-        for (int j = 0; j < 3; j++) xt[j] = (_Float16 *)pool.take_n<float>((size_t)Lo * Cp);   // f16 xt, or f32 ping-pong partner of y (fused path)
+        for (int j = 0; j < 3; j++) y[j] = pool.take_n<float>(Lo * Cp);
+        for (int j = 0; j < 3; j++) xt[j] = (_Float16 *)pool.take_n<float>(Lo * Cp);   // f16 xt, or f32 ping-pong partner of y (fused path)
 
         // V1: leaky_relu(0.1) -> transposed conv (polyphase) + bias      (src/hifigan.cpp:281-297, 22-71)
         {
-            ConvJob j = job(up, L);
+            ConvJob j = job(up);
             j.slope = 0.1f;
             if (i == 0) { j.x0 = c0; j.pro = PRO_ACT; }
             else { j.x0 = prev_y[0]; j.x1 = prev_y[1]; j.x2 = prev_y[2]; j.pro = PRO_SUM3_ACT; j.pscale = third; }
             j.out = ub;
             // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
-            conv(&j, 1, "voc_upsample", 4.0 * L * C * (i == 0 ? 1 : 3) + 4.0 * Lo * Cout + 2.0 * C * Cout * 2 * s,
+            conv(&j, 1, fr, rate, "voc_upsample", 4.0 * L * C * (i == 0 ? 1 : 3) + 4.0 * Lo * Cout + 2.0 * C * Cout * 2 * s,
                  2.0 * L * C * Cout * 2 * s);
         }
         L = Lo;
+        rate *= s;
         C = Cout;
+        const long Lbatch = (long)bt.t_max * rate * bt.nseg;       // rows the launches of this stage cover
 
         // V2: the 3 MRF branches run side by side (one job each).  Fused path: one launch per dilation
         // (conv -> lrelu -> conv -> + residual, xt kept in LDS), y ping-pongs between two buffers because a
@@ -756,12 +789,12 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         // 256-channel stage: the fused kernel needs all 256 xt channels in one workgroup, which leaves only
         // ceil(L/54) workgroups per branch — measured slower than two unfused launches (480 workgroups) until the
         // stage has enough rows to give every CU two of them (long / batched utterances)
-        const bool enough_rows = Cp != 256 || force_fuse256_ || (long)(L / 54) * 3 >= 2L * n_cu;
+        const bool enough_rows = Cp != 256 || force_fuse256_ || (Lbatch / 54) * 3 >= 2L * n_cu;
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
         group_begin();
         // narrow stages: the whole residual block (all dilations) of the three branches in ONE launch, y tile kept
-        // in LDS between the dilation pairs (launch_triple)
+        // in registers between the dilation pairs (launch_triple)
         bool whole_block = fused && !no_triple_ && voc_.n_dil <= TRIPLE_MAX_DIL;
         for (int jb = 0; jb < 3 && whole_block; jb++)
         {
@@ -781,7 +814,6 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 t.y = ub;
                 t.out = y[jb];
                 t.n_dil = voc_.n_dil;
-                t.L = L;
                 t.Cp = Cp;
                 t.slope = 0.1f;
                 for (int d = 0; d < voc_.n_dil; d++)
@@ -793,12 +825,12 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                     t.b1[d] = rp.c1.bias;
                     t.b2[d] = rp.c2.bias;
                     t.dil[d] = voc_.dil[d];
-                    bb += conv_bytes(L, C, C, rp.c1.K, false) + conv_bytes(L, C, C, rp.c2.K, true);
-                    ff += conv_flops(L, C, C, rp.c1.K) + conv_flops(L, C, C, rp.c2.K);
+                    bb += conv_bytes((double)L, C, C, rp.c1.K, false) + conv_bytes((double)L, C, C, rp.c2.K, true);
+                    ff += conv_flops((double)L, C, C, rp.c1.K) + conv_flops((double)L, C, C, rp.c2.K);
                 }
                 ycur[jb] = y[jb];
             }
-            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu));
+            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate));
         }
         for (int d = 0; d < voc_.n_dil && !whole_block; d++)
         {
@@ -812,7 +844,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 float *yout = fused ? ((d & 1) ? (float *)xt[jb] : y[jb]) : y[jb];
                 if (fused && !rp.p1) fail(ZV_ERR_SHAPE, "residual block %d: branches of one stage must all be fusable", i * voc_.n_rb + jb);
                 // xt = lrelu(conv(lrelu(y), k, dil) + b)  kept as the f16 operand of the next conv (:108-150)
-                ConvJob a = job(rp.c1, L);
+                ConvJob a = job(rp.c1);
                 a.x0 = yin;
                 a.pro = PRO_ACT;
                 a.slope = 0.1f;
@@ -824,7 +856,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 a.out = xt[jb];
                 j1[jb] = a;
                 // y = y + (conv(xt, k, 1) + b)                                                    (:169-181)
-                ConvJob b = job(rp.c2, L);
+                ConvJob b = job(rp.c2);
                 b.x0 = xt[jb];
                 b.pro = PRO_RAW_F16;
                 b.res = yin;
@@ -839,23 +871,22 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
                 p.w2 = rp.p2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
-                p.L = L;
                 p.Cp = Cp;
                 p.K = rp.c1.K;
                 p.dil = voc_.dil[d];
                 p.slope = 0.1f;
                 ycur[jb] = fused ? yout : y[jb];
-                b1 += conv_bytes(L, C, C, rp.c1.K, false);
-                f1 += conv_flops(L, C, C, rp.c1.K);
-                b2 += conv_bytes(L, C, C, rp.c2.K, true);
-                f2 += conv_flops(L, C, C, rp.c2.K);
+                b1 += conv_bytes((double)L, C, C, rp.c1.K, false);
+                f1 += conv_flops((double)L, C, C, rp.c1.K);
+                b2 += conv_bytes((double)L, C, C, rp.c2.K, true);
+                f2 += conv_flops((double)L, C, C, rp.c2.K);
             }
             if (fused)
-                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu));
+                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate));
             else
             {
-                conv(j1, 3, "voc_resblock_conv", b1, f1);
-                conv(j2, 3, "voc_resblock_conv", b2, f2);
+                conv(j1, 3, fr, rate, "voc_resblock_conv", b1, f1);
+                conv(j2, 3, fr, rate, "voc_resblock_conv", b2, f2);
             }
         }
         group_end("voc_resblock_conv");
@@ -870,7 +901,7 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         a.x1 = prev_y[1];
         a.x2 = prev_y[2];
         a.ldx = round_up(C, 16);
-        a.L = L;
+        a.L = 0;
         a.C = C;
         a.K = voc_.out_K;
         a.pscale = third;
@@ -878,6 +909,8 @@ void Model::vocode_dev(const float *d_mel, uint32_t T, float *d_wav)
         a.w = voc_.out_w;
         a.bias = voc_.out_b;
         a.out = d_wav;
+        a.segs = fr;
+        a.rate = rate;
         ZV_LAUNCH("voc_output_conv", 12.0 * L * C + 4.0 * L, 2.0 * L * C * a.K, launch_out_conv(stream, a));
     }
 }
@@ -887,38 +920,30 @@ void Model::drop_graphs()
     for (auto &g : graphs_)
         if (g.exec) hipGraphExecDestroy(g.exec);
     graphs_.clear();
-    for (auto &g : chain_graphs_)
-        if (g.exec) hipGraphExecDestroy(g.exec);
-    chain_graphs_.clear();
 }
 
-void Model::chain_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
-                      float *d_hidden, float *d_mel, float *d_wav, int32_t *d_nframes)
+// Replays the captured schedule for (kind, capacities, buffers) or captures it first.  The capacities decide grids and
+// arena layout; the segment tables are read by the kernels at run time, so a batch graph does not depend on the
+// utterances' lengths.
+template <typename F> void Model::run_captured(int kind, const Batch &b, const void *const *key, int nkey, F &&enqueue)
 {
-    auto run = [&]() {
-        EncoderTaps t = encode_dev(d_ids, d_puncts, d_style, N, T, d_hidden);
-        ZV_HIP(hipMemcpyAsync(d_nframes, t.n_frames, 4, hipMemcpyDeviceToDevice, stream));
-        decode_dev(d_hidden, d_style, T, d_mel);       // the reference vocodes all T frames (src/zerovox.cpp:326-334)
-        vocode_dev(d_mel, T, d_wav);
-    };
-    if (!graph_mode || profiling || cur_lane_ != 0)
-    {
-        run();
-        return;
-    }
-    const void *key[7] = {d_ids, d_puncts, d_style, d_hidden, d_mel, d_wav, d_nframes};
-    for (auto &g : chain_graphs_)
-        if (g.N == N && g.T == T && memcmp(g.p, key, sizeof(key)) == 0)
+    const void *kp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < nkey && i < 8; i++) kp[i] = key[i];
+    for (auto &g : graphs_)
+        if (g.kind == kind && g.b.nseg == b.nseg && g.b.n_max == b.n_max && g.b.t_max == b.t_max && g.b.n_rows == b.n_rows &&
+            g.b.t_rows == b.t_rows && g.b.d_tok == b.d_tok && g.b.d_frm == b.d_frm &&
+            (b.d_tok || memcmp(&g.b.tok1, &b.tok1, sizeof(Seg)) == 0) && (b.d_frm || memcmp(&g.b.frm1, &b.frm1, sizeof(Seg)) == 0) &&
+            memcmp(g.p, kp, sizeof(kp)) == 0)
         {
             ZV_HIP(hipGraphLaunch(g.exec, stream));
             return;
         }
-    arena_require(arena_bytes_for(N, T));        // hipMalloc is not capturable
+    reserve_batch(b);                            // hipMalloc is not capturable
     hipGraph_t graph = nullptr;
     ZV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     try
     {
-        run();
+        enqueue();
     }
     catch (...)
     {
@@ -927,191 +952,236 @@ void Model::chain_dev(const int32_t *d_ids, const int32_t *d_puncts, const float
         throw;
     }
     ZV_HIP(hipStreamEndCapture(stream, &graph));
-    ChainGraph cg;
-    cg.N = N;
-    cg.T = T;
-    memcpy(cg.p, key, sizeof(key));
+    CapturedGraph cg;
+    cg.kind = kind;
+    cg.b = b;
+    memcpy(cg.p, kp, sizeof(kp));
     hipError_t e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) fail(ZV_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    if (chain_graphs_.size() >= 16) drop_graphs();
-    chain_graphs_.push_back(cg);
+    if (graphs_.size() >= 16)
+    {
+        // the oldest graphs may still be executing: drain the stream before their execs go away
+        ZV_HIP(hipStreamSynchronize(stream));
+        drop_graphs();
+    }
+    graphs_.push_back(cg);
     ZV_HIP(hipGraphLaunch(cg.exec, stream));
 }
 
-void Model::vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav)
+void Model::chain_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles, float *d_hidden,
+                      float *d_mel, float *d_wav, int32_t *d_nframes, const void *h2d_src, void *h2d_dst, size_t h2d_bytes)
 {
-    if (!graph_mode || profiling || cur_lane_ != 0)
+    auto run = [&]() {
+        if (h2d_bytes) ZV_HIP(hipMemcpyAsync(h2d_dst, h2d_src, h2d_bytes, hipMemcpyHostToDevice, stream));
+        encode_dev(b, d_ids, d_puncts, d_styles, d_hidden, d_nframes);
+        decode_dev(b, d_hidden, d_styles, d_mel);        // the reference vocodes all T frames (src/zerovox.cpp:326-334)
+        vocode_dev(b, d_mel, d_wav);
+    };
+    if (!graph_mode || profiling)
     {
-        vocode_dev(d_mel, T, d_wav);
+        run();
         return;
     }
-    for (auto &g : graphs_)
-        if (g.T == T && g.mel == d_mel && g.wav == d_wav)
-        {
-            ZV_HIP(hipGraphLaunch(g.exec, stream));
-            return;
-        }
-    arena_require(arena_bytes_for(1, T));        // outside the capture: hipMalloc is not capturable
-    hipGraph_t graph = nullptr;
-    ZV_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    try
+    const void *key[8] = {d_ids, d_puncts, d_styles, d_hidden, d_mel, d_wav, d_nframes, h2d_src};
+    run_captured(1, b, key, 8, run);
+}
+
+void Model::vocode_dev_graph(const Batch &b, const float *d_mel, float *d_wav)
+{
+    if (!graph_mode || profiling)
     {
-        vocode_dev(d_mel, T, d_wav);
+        vocode_dev(b, d_mel, d_wav);
+        return;
     }
-    catch (...)
-    {
-        hipStreamEndCapture(stream, &graph);
-        if (graph) hipGraphDestroy(graph);
-        throw;
-    }
-    ZV_HIP(hipStreamEndCapture(stream, &graph));
-    VocoderGraph vg;
-    vg.T = T;
-    vg.mel = d_mel;
-    vg.wav = d_wav;
-    hipError_t e = hipGraphInstantiate(&vg.exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (e != hipSuccess) fail(ZV_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    if (graphs_.size() >= 16) drop_graphs();
-    graphs_.push_back(vg);
-    ZV_HIP(hipGraphLaunch(vg.exec, stream));
+    const void *key[2] = {d_mel, d_wav};
+    run_captured(0, b, key, 2, [&]() { vocode_dev(b, d_mel, d_wav); });
 }
 
 // ---------------------------------------------------------------------------------------------------
 // StyleTTS mel decoder (reference src/stylettsdec.cpp:306-470)
 
-void Model::decode_dev(const float *d_hidden, const float *d_style, uint32_t T, float *d_mel)
+void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_styles, float *d_mel)
 {
-    if (T == 0) fail(ZV_ERR_ARG, "T must be > 0");
-    arena_require(arena_bytes_for(1, T));
+    if (bt.t_rows == 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "T must be > 0");
+    arena_require(arena_bytes_for(1, bt.t_rows, bt.nseg));
     arena_.used = 0;
-    const int Ed = (int)E(), B = 2 * Ed, R = dec_.R, CAT = B + R, L = (int)T;
-    float *h = arena_.take_n<float>(dec_.fc_out + 64);
-    float *st1 = arena_.take_n<float>(2 * CAT + 64), *st2 = arena_.take_n<float>(2 * CAT + 64);
-    float *cat = arena_.take_n<float>((size_t)L * CAT);
-    float *t1 = arena_.take_n<float>((size_t)L * B);
-    float *sc = arena_.take_n<float>((size_t)L * B);
-    float *x0 = arena_.take_n<float>((size_t)L * B);
-    float *xa = arena_.take_n<float>((size_t)L * B);
-    float *asr_t = arena_.take_n<float>((size_t)L * R);
+    const Segs fr = bt.frames();
+    const int Ed = (int)E(), B = 2 * Ed, R = dec_.R, CAT = B + R, S = bt.nseg;
+    const size_t L = bt.t_rows;
+    const int nblk = (bt.t_max + 31) / 32;                         // statistics blocks per segment
+    const int hs = round_up(dec_.fc_out + 64, 64);                 // AdaIN vectors per segment
+    const int ss = 2 * CAT + 64;                                   // (mean, rstd) pairs per segment
+    float *h = arena_.take_n<float>((size_t)S * hs);
+    float *st_x = arena_.take_n<float>((size_t)S * ss), *st_t = arena_.take_n<float>((size_t)S * ss);
+    float *st_y = arena_.take_n<float>((size_t)S * ss), *st_a = arena_.take_n<float>((size_t)S * ss);
+    double *part_t = arena_.take_n<double>((size_t)S * nblk * CAT * 2), *part_o = arena_.take_n<double>((size_t)S * nblk * CAT * 2);
+    float *cat = arena_.take_n<float>(L * CAT);
+    float *t1 = arena_.take_n<float>(L * B);
+    float *sc = arena_.take_n<float>(L * B);
+    float *x0 = arena_.take_n<float>(L * B);
+    float *xa = arena_.take_n<float>(L * B);
+    float *asr_t = arena_.take_n<float>(L * R);
+    const double Ld = (double)L;
 
-    // D2: all ten AdaIN fc layers at once (depends only on the style vector)     (src/stylettsdec.cpp:175-189)
-    ZV_LAUNCH("dec_adain_fc", 4.0 * dec_.fc_out * (Ed + 2), 2.0 * dec_.fc_out * Ed,
-              launch_linear(stream, d_style, Ed, 1, Ed, dec_.fcW, dec_.fcB, dec_.fc_out, h, dec_.fc_out, dec_.fcExtra));
+    // D2: all ten AdaIN fc layers at once for every utterance's style vector            (src/stylettsdec.cpp:175-189)
+    ZV_LAUNCH("dec_adain_fc", 4.0 * dec_.fc_out * (Ed + 2), 2.0 * S * dec_.fc_out * Ed,
+              launch_linear(stream, d_styles, Ed, Ed, dec_.fcW, dec_.fcB, dec_.fc_out, h, hs, dec_.fcExtra, segs_single(S)));
 
     const float rsqrt2 = (float)(1.0 / sqrt(2.0));                       // src/stylettsdec.cpp:146,301
 
-    // one residual block: IN/AdaIN -> lrelu -> conv1 -> IN/AdaIN -> lrelu -> conv2 -> (+ shortcut) / sqrt2
-    auto block = [&](const DecBlk &b, const float *x, int ldx, const float *g1, const float *b1, const float *g2,
-                     const float *b2, float *out, int ldo) {
-        ZV_LAUNCH("dec_in_stats", 4.0 * L * b.cin, 3.0 * L * b.cin, launch_in_stats(stream, x, ldx, L, b.cin, 1e-5f, st1));
+    auto finalize = [&](const double *part, int C, float *stat, int c_off) {
+        ZV_LAUNCH("dec_in_stats", 16.0 * S * nblk * C, 4.0 * S * nblk * C,
+                  launch_stats_finalize(stream, part, nblk, C, 1e-5f, stat, ss, c_off, fr, 1));
+    };
+
+    // InstanceNorm statistics of the stage input (it comes from the encoder or the host, not from a conv of ours)
+    ZV_LAUNCH("dec_in_stats", 4.0 * Ld * Ed, 3.0 * Ld * Ed, launch_stats_partial(stream, d_hidden, Ed, Ed, part_o, nblk, fr, 1));
+    finalize(part_o, Ed, st_x, 0);
+
+    // one residual block: IN/AdaIN -> lrelu -> conv1 -> IN/AdaIN -> lrelu -> conv2 -> (+ shortcut) / sqrt2.
+    // `st_in` holds the statistics of x; the statistics of the block's output land in `st_out` (channels c_off ...)
+    // through the conv epilogue's partial sums when `st_out` is given.  gb_seg: per-segment stride of the affine vectors
+    // (0 for the encode blocks' shared InstanceNorm weights, hs for the decode blocks' AdaIN vectors).
+    auto block = [&](const DecBlk &b, const float *x, int ldx, const float *st_in, const float *g1, const float *b1,
+                     const float *g2, const float *b2, int gb_seg, float *out, int ldo, float *st_out, int c_off) {
         const float *res = x;
         int ldres = ldx;
+        ConvJob jj[2];
+        int nj = 0;
+        {
+            ConvJob j = job(b.conv1);
+            j.x0 = x;
+            j.ldx = ldx;
+            j.pro = PRO_NORM_ACT;
+            j.pstat = st_in;
+            j.pstat_seg = ss;
+            j.pa = g1;
+            j.pb = b1;
+            j.pab_seg = gb_seg;
+            j.slope = 0.2f;
+            j.out = t1;
+            j.stat_part = part_t;
+            j.stat_nblk = nblk;
+            j.stat_C = b.conv1.Cout;
+            jj[nj++] = j;
+        }
+        double bytes = conv_bytes(Ld, b.cin, b.conv1.Cout, 3, false), flops = conv_flops(Ld, b.cin, b.conv1.Cout, 3);
         if (b.learned_sc)
         {
-            ConvJob j = job(b.sc, L);
-            j.allow_splitk = 1;
+            ConvJob j = job(b.sc);
             j.x0 = x;
             j.ldx = ldx;
             j.out = sc;
-            conv(&j, 1, "dec_conv", conv_bytes(L, b.cin, b.cout, 1, false), conv_flops(L, b.cin, b.cout, 1));
             res = sc;
             ldres = b.sc.Cout_p;
+            const double sb = conv_bytes(Ld, b.cin, b.cout, 1, false), sf = conv_flops(Ld, b.cin, b.cout, 1);
+            if (b.sc.Cout_p == b.conv1.Cout_p)
+            {   // same output width as conv1: second job of the same launch
+                jj[nj++] = j;
+                bytes += sb;
+                flops += sf;
+            }
+            else
+                conv(&j, 1, fr, 1, "dec_conv", sb, sf);
         }
-        {
-            ConvJob j = job(b.conv1, L);
-            j.allow_splitk = 1;
-            j.x0 = x;
-            j.ldx = ldx;
-            j.pro = PRO_NORM_ACT;
-            j.pstat = st1;
-            j.pa = g1;
-            j.pb = b1;
-            j.slope = 0.2f;
-            j.out = t1;
-            conv(&j, 1, "dec_conv", conv_bytes(L, b.cin, b.conv1.Cout, 3, false), conv_flops(L, b.cin, b.conv1.Cout, 3));
-        }
+        conv(jj, nj, fr, 1, "dec_conv", bytes, flops);
         const int Cm = b.conv1.Cout;
-        ZV_LAUNCH("dec_in_stats", 4.0 * L * Cm, 3.0 * L * Cm, launch_in_stats(stream, t1, b.conv1.Cout_p, L, Cm, 1e-5f, st2));
+        finalize(part_t, Cm, st_t, 0);
         {
-            ConvJob j = job(b.conv2, L);
-            j.allow_splitk = 1;
+            ConvJob j = job(b.conv2);
             j.x0 = t1;
             j.ldx = b.conv1.Cout_p;
             j.pro = PRO_NORM_ACT;
-            j.pstat = st2;
+            j.pstat = st_t;
+            j.pstat_seg = ss;
             j.pa = g2;
             j.pb = b2;
+            j.pab_seg = gb_seg;
             j.slope = 0.2f;
             j.res = res;
             j.ldres = ldres;
             j.escale = rsqrt2;
             j.out = out;
             j.ldo = ldo;
-            conv(&j, 1, "dec_conv", conv_bytes(L, Cm, b.cout, 3, true), conv_flops(L, Cm, b.cout, 3));
+            if (st_out)
+            {
+                j.stat_part = part_o;
+                j.stat_nblk = nblk;
+                j.stat_C = b.cout;
+            }
+            conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Cm, b.cout, 3, true), conv_flops(Ld, Cm, b.cout, 3));
         }
+        if (st_out) finalize(part_o, b.cout, st_out, c_off);
     };
 
     // encode0 / encode1: ResBlk1d with affine InstanceNorm                         (src/stylettsdec.cpp:69-149,373-374)
-    block(dec_.enc[0], d_hidden, Ed, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, x0, B);
-    block(dec_.enc[1], x0, B, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, cat, CAT);
+    block(dec_.enc[0], d_hidden, Ed, st_x, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, 0, x0, B, st_y, 0);
+    block(dec_.enc[1], x0, B, st_y, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, 0, cat, CAT, st_x, 0);
 
     // asr_res = IN_affine(conv1x1(enc_seq) + b) written straight into the concat buffer      (:382-404)
     {
-        ConvJob j = job(dec_.asr0, L);
-        j.allow_splitk = 1;
+        ConvJob j = job(dec_.asr0);
         j.x0 = d_hidden;
         j.ldx = Ed;
         j.out = asr_t;
-        conv(&j, 1, "dec_conv", conv_bytes(L, Ed, R, 1, false), conv_flops(L, Ed, R, 1));
-        ZV_LAUNCH("dec_in_stats", 4.0 * L * R, 3.0 * L * R, launch_in_stats(stream, asr_t, R, L, R, 1e-5f, st1));
-        ZV_LAUNCH("dec_norm_apply", 8.0 * L * R, 3.0 * L * R,
-                  launch_norm_apply(stream, asr_t, R, L, R, st1, dec_.asr1w, dec_.asr1b, cat + B, CAT));
+        j.stat_part = part_t;
+        j.stat_nblk = nblk;
+        j.stat_C = R;
+        conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Ed, R, 1, false), conv_flops(Ld, Ed, R, 1));
+        finalize(part_t, R, st_a, 0);
+        ZV_LAUNCH("dec_norm_apply", 8.0 * Ld * R, 3.0 * Ld * R,
+                  launch_norm_apply(stream, asr_t, R, R, st_a, ss, dec_.asr1w, dec_.asr1b, cat + B, CAT, part_t, nblk, fr));
+        finalize(part_t, R, st_x, B);            // statistics of the concat's asr columns: valid for decode0..2
     }
 
     // decode0..4: AdainResBlk1d; blocks 0..2 read cat([x, asr]) and 0,1 write x back into it   (:406-428)
     const float *cur = cat;
     int ldc = CAT;
+    const float *st_cur = st_x;
     float *outs[5] = {cat, cat, xa, x0, xa};
     const int ldos[5] = {CAT, CAT, Ed, Ed, Ed};
+    float *sts[5] = {st_x, st_x, st_y, st_x, nullptr};      // decode0/1 refresh the x columns of the concat's statistics
     for (int i = 0; i < 5; i++)
     {
         const DecBlk &b = dec_.dec[i];
-        block(b, cur, ldc, h + b.g1, h + b.g1 + b.cin, h + b.g2, h + b.g2 + b.cout, outs[i], ldos[i]);
+        block(b, cur, ldc, st_cur, h + b.g1, h + b.g1 + b.cin, h + b.g2, h + b.g2 + b.cout, hs, outs[i], ldos[i], sts[i], 0);
         cur = outs[i];
         ldc = ldos[i];
+        st_cur = sts[i];
     }
     // to_out: conv1x1 E -> num_mels + b, emitted frame-major                                       (:432-441)
     {
-        ConvJob j = job(dec_.to_out, L);
-        j.allow_splitk = 1;
+        ConvJob j = job(dec_.to_out);
         j.x0 = cur;
         j.ldx = ldc;
         j.out = d_mel;
         j.ldo = dec_.M;
-        conv(&j, 1, "dec_conv", conv_bytes(L, Ed, dec_.M, 1, false), conv_flops(L, Ed, dec_.M, 1));
+        conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Ed, dec_.M, 1, false), conv_flops(Ld, Ed, dec_.M, 1));
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // FastSpeech2 encoder + variance adaptor + length regulator (reference src/fs2encoder.cpp:289-336,477-656)
 
-Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N,
-                                     uint32_t T, float *d_hidden)
+Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles,
+                                     float *d_hidden, int32_t *d_nframes)
 {
-    if (N == 0 || T == 0) fail(ZV_ERR_ARG, "N and T must be > 0");
-    if ((int)N > enc_.posenc_rows) fail(ZV_ERR_ARG, "%u phonemes exceed the %d rows of the sinusoid table", N, enc_.posenc_rows);
-    arena_require(arena_bytes_for(N, T));
+    if (bt.n_rows == 0 || bt.t_rows == 0 || bt.n_max <= 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "N and T must be > 0");
+    if (bt.n_max > enc_.posenc_rows) fail(ZV_ERR_ARG, "%d phonemes exceed the %d rows of the sinusoid table", bt.n_max, enc_.posenc_rows);
+    arena_require(arena_bytes_for(bt.n_rows, bt.t_rows, bt.nseg));
     arena_.used = 0;
-    const int Ed = (int)E(), n = (int)N, H = hp.encoder_head, dk = Ed / H;
+    const Segs tk = bt.tokens(), fr = bt.frames();
+    const int Ed = (int)E(), H = hp.encoder_head, dk = Ed / H;
+    const size_t n = bt.n_rows;
+    const double nd = (double)n;
     const int Fp = round_up(hp.conv_filter_size, 16);
-    float *x = arena_.take_n<float>((size_t)n * Ed), *y = arena_.take_n<float>((size_t)n * Ed);
-    float *qkv = arena_.take_n<float>((size_t)n * 3 * Ed), *o = arena_.take_n<float>((size_t)n * Ed);
-    float *f = arena_.take_n<float>((size_t)n * Ed);
-    _Float16 *hh = arena_.take_n<_Float16>((size_t)n * Fp);
+    float *x = arena_.take_n<float>(n * Ed), *y = arena_.take_n<float>(n * Ed);
+    float *qkv = arena_.take_n<float>(n * 3 * Ed), *o = arena_.take_n<float>(n * Ed);
+    float *f = arena_.take_n<float>(n * Ed);
+    _Float16 *hh = arena_.take_n<_Float16>(n * Fp);
     const int Vp = round_up(enc_.dur.V, 16);
-    float *va = arena_.take_n<float>((size_t)n * Vp), *vb = arena_.take_n<float>((size_t)n * Vp);
+    float *va = arena_.take_n<float>(n * Vp), *vb = arena_.take_n<float>(n * Vp);
     EncoderTaps t;
     t.features = x;
     t.logdur = arena_.take_n<float>(n);
@@ -1119,75 +1189,71 @@ Model::EncoderTaps Model::encode_dev(const int32_t *d_ids, const int32_t *d_punc
     t.energy = arena_.take_n<float>(n);
     t.pitch_bucket = arena_.take_n<int32_t>(n);
     t.energy_bucket = arena_.take_n<int32_t>(n);
-    t.n_frames = arena_.take_n<int32_t>(n + 1);
+    t.cum = arena_.take_n<int32_t>(n);
 
-    ZV_LAUNCH("enc_embed", 8.0 * n * Ed, 1.0 * n * Ed,
-              launch_embed(stream, d_ids, d_puncts, enc_.wemb, hp.emb_dim, enc_.pemb, hp.punct_emb_dim, enc_.posenc, n, x, Ed));
+    ZV_LAUNCH("enc_embed", 8.0 * nd * Ed, 1.0 * nd * Ed,
+              launch_embed(stream, d_ids, d_puncts, enc_.wemb, hp.emb_dim, enc_.pemb, hp.punct_emb_dim, enc_.posenc, x, Ed, tk));
     const float temperature = (float)pow((double)dk, 0.5);               // src/fs2encoder.cpp:66
     const float inv_t = (float)(1.0 / temperature);                      // :107
     for (const EncLayer &Ly : enc_.layers)
     {
-        ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * n * Ed), 6.0 * n * Ed * Ed,
-                  launch_linear(stream, x, Ed, n, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr));
-        ZV_LAUNCH("enc_attention", 16.0 * n * Ed, 4.0 * n * n * Ed,
-                  launch_attention(stream, qkv, qkv + Ed, qkv + 2 * Ed, 3 * Ed, n, H, dk, inv_t, o, Ed));
-        ZV_LAUNCH("enc_linear", 4.0 * (1.0 * Ed * Ed + 2.0 * n * Ed), 2.0 * n * Ed * Ed,
-                  launch_linear(stream, o, Ed, n, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr));
-        ZV_LAUNCH("enc_layernorm", 12.0 * n * Ed, 8.0 * n * Ed,
-                  launch_add_layernorm(stream, f, Ed, x, Ed, n, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed));
+        ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * nd * Ed), 6.0 * nd * Ed * Ed,
+                  launch_linear(stream, x, Ed, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr, tk));
+        ZV_LAUNCH("enc_attention", 16.0 * nd * Ed, 4.0 * nd * bt.n_max * Ed,
+                  launch_attention(stream, qkv, qkv + Ed, qkv + 2 * Ed, 3 * Ed, H, dk, inv_t, o, Ed, tk));
+        ZV_LAUNCH("enc_linear", 4.0 * (1.0 * Ed * Ed + 2.0 * nd * Ed), 2.0 * nd * Ed * Ed,
+                  launch_linear(stream, o, Ed, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr, tk));
+        ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
+                  launch_add_layernorm(stream, f, Ed, x, Ed, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed, tk));
         {   // FFN: conv k9 + b -> relu (kept as f16 operand) -> conv k1 + b            (src/fs2encoder.cpp:190-214)
-            ConvJob a = job(Ly.w1, n);
-            a.allow_splitk = 1;
+            ConvJob a = job(Ly.w1);
             a.x0 = y;
             a.eact = 1;
             a.oslope = 0.f;
             a.out_f16 = 1;
             a.out = hh;
-            conv(&a, 1, "enc_conv", conv_bytes(n, Ed, Ly.w1.Cout, Ly.w1.K, false), conv_flops(n, Ed, Ly.w1.Cout, Ly.w1.K));
-            ConvJob b = job(Ly.w2, n);
-            b.allow_splitk = 1;
+            conv(&a, 1, tk, 1, "enc_conv", conv_bytes(nd, Ed, Ly.w1.Cout, Ly.w1.K, false), conv_flops(nd, Ed, Ly.w1.Cout, Ly.w1.K));
+            ConvJob b = job(Ly.w2);
             b.x0 = hh;
             b.pro = PRO_RAW_F16;
             b.out = f;
-            conv(&b, 1, "enc_conv", conv_bytes(n, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(n, Ly.w1.Cout, Ed, Ly.w2.K));
+            conv(&b, 1, tk, 1, "enc_conv", conv_bytes(nd, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(nd, Ly.w1.Cout, Ed, Ly.w2.K));
         }
-        ZV_LAUNCH("enc_layernorm", 12.0 * n * Ed, 8.0 * n * Ed,
-                  launch_add_layernorm(stream, f, Ed, y, Ed, n, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed));
+        ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
+                  launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk));
     }
     // features = encoder output + style_embed                                             (:550-552)
-    ZV_LAUNCH("enc_add_style", 8.0 * n * Ed, 1.0 * n * Ed, launch_add_rowvec(stream, x, Ed, n, Ed, d_style));
+    ZV_LAUNCH("enc_add_style", 8.0 * nd * Ed, 1.0 * nd * Ed, launch_add_rowvec(stream, x, Ed, Ed, d_styles, Ed, tk));
 
     auto predictor = [&](const VarPred &v, float *out) {        // VariancePredictor::graph (:386-440)
-        ConvJob a = job(v.c1, n);
-        a.allow_splitk = 1;
+        ConvJob a = job(v.c1);
         a.x0 = x;
         a.eact = 1;
         a.oslope = 0.f;
         a.out = va;
-        conv(&a, 1, "enc_conv", conv_bytes(n, Ed, v.V, 3, false), conv_flops(n, Ed, v.V, 3));
-        ZV_LAUNCH("enc_layernorm", 8.0 * n * v.V, 8.0 * n * v.V,
-                  launch_add_layernorm(stream, va, Vp, nullptr, 0, n, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp));
-        ConvJob b = job(v.c2, n);
-        b.allow_splitk = 1;
+        conv(&a, 1, tk, 1, "enc_conv", conv_bytes(nd, Ed, v.V, 3, false), conv_flops(nd, Ed, v.V, 3));
+        ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp, tk));
+        ConvJob b = job(v.c2);
         b.x0 = vb;
         b.pad = 1;                                              // literal 1 in the reference (:417)
         b.eact = 1;
         b.oslope = 0.f;
         b.out = va;
-        conv(&b, 1, "enc_conv", conv_bytes(n, v.V, v.V, 3, false), conv_flops(n, v.V, v.V, 3));
-        ZV_LAUNCH("enc_layernorm", 8.0 * n * v.V, 8.0 * n * v.V,
-                  launch_add_layernorm(stream, va, Vp, nullptr, 0, n, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp));
-        ZV_LAUNCH("enc_rowdot", 4.0 * n * v.V, 2.0 * n * v.V, launch_rowdot(stream, vb, Vp, n, v.V, v.lw, v.lb, out));
+        conv(&b, 1, tk, 1, "enc_conv", conv_bytes(nd, v.V, v.V, 3, false), conv_flops(nd, v.V, v.V, 3));
+        ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tk));
+        ZV_LAUNCH("enc_rowdot", 4.0 * nd * v.V, 2.0 * nd * v.V, launch_rowdot(stream, vb, Vp, v.V, v.lw, v.lb, out, tk));
     };
     predictor(enc_.dur, t.logdur);
     predictor(enc_.pitch, t.pitch);
-    ZV_LAUNCH("enc_bucket_embed", 12.0 * n * Ed, 1.0 * n * Ed,
-              launch_bucket_embed_add(stream, t.pitch, n, hp.encoder_ve_n_bins, enc_.pitch_emb, Ed, x, Ed, t.pitch_bucket));
+    ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
+              launch_bucket_embed_add(stream, t.pitch, hp.encoder_ve_n_bins, enc_.pitch_emb, Ed, x, Ed, t.pitch_bucket, tk));
     predictor(enc_.energy, t.energy);                           // sees the pitch-augmented features (:569-572)
-    ZV_LAUNCH("enc_bucket_embed", 12.0 * n * Ed, 1.0 * n * Ed,
-              launch_bucket_embed_add(stream, t.energy, n, hp.encoder_ve_n_bins, enc_.energy_emb, Ed, x, Ed, t.energy_bucket));
-    ZV_LAUNCH("enc_length_regulator", 4.0 * (n + T) * Ed, 0.0,
-              launch_length_regulator(stream, x, Ed, t.logdur, n, Ed, (int)T, d_hidden, Ed, t.n_frames));
+    ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
+              launch_bucket_embed_add(stream, t.energy, hp.encoder_ve_n_bins, enc_.energy_emb, Ed, x, Ed, t.energy_bucket, tk));
+    ZV_LAUNCH("enc_length_regulator", 4.0 * (nd + (double)bt.t_rows) * Ed, 0.0,
+              launch_length_regulator(stream, x, Ed, t.logdur, Ed, d_hidden, Ed, t.cum, d_nframes, tk, fr));
     return t;
 }
 

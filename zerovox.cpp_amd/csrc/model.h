@@ -47,19 +47,40 @@ struct ProfEntry
     int         launches;       // consecutive launches of the same family bracketed by this event pair
 };
 
-struct ChainGraph
+// One call's utterances (host side).  Tensors of a batch are row-concatenated: utterance u owns the token rows /
+// frame rows its table entries name (kernels.h: Seg / Segs).  `nseg`, `n_max`, `t_max`, `n_rows`, `t_rows` are
+// CAPACITIES: they size grids and the arena, the real extents are read from the tables on the device, so one captured
+// graph serves every batch that fits.  A single utterance needs no table (inline segment).
+struct Batch
 {
-    uint32_t       N = 0, T = 0;
-    const void    *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipGraphExec_t exec = nullptr;
+    int        nseg = 1;
+    int        n_max = 0, t_max = 0;        // >= every utterance's phonemes / frames
+    size_t     n_rows = 0, t_rows = 0;      // >= sum of phonemes / frames (rows of the concatenated buffers)
+    const Seg *d_tok = nullptr, *d_frm = nullptr;
+    Seg        tok1{0, 0, 0, 0}, frm1{0, 0, 0, 0};
+
+    static Batch single(uint32_t N, uint32_t T, uint32_t num_phonemes)
+    {
+        Batch b;
+        b.n_max = (int)N;
+        b.t_max = (int)T;
+        b.n_rows = N;
+        b.t_rows = T;
+        b.tok1 = Seg{0, (int32_t)N, (int32_t)num_phonemes, 0};
+        b.frm1 = Seg{0, (int32_t)T, 0, 0};
+        return b;
+    }
+    Segs tokens() const { return Segs{d_tok, nseg, n_max, tok1}; }
+    Segs frames() const { return Segs{d_frm, nseg, t_max, frm1}; }
 };
 
-struct VocoderGraph
+// a captured schedule: replayed when the same entry point is called with the same capacities and buffers
+struct CapturedGraph
 {
-    uint32_t        T = 0;
-    const float    *mel = nullptr;
-    float          *wav = nullptr;
-    hipGraphExec_t  exec = nullptr;
+    int            kind = 0;               // 0 vocoder, 1 chain
+    Batch          b;
+    const void    *p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t exec = nullptr;
 };
 
 class Model
@@ -74,18 +95,26 @@ class Model
     hipStream_t stream = nullptr;
 
     // ---- stages (device pointers in, device pointers out; everything enqueued on `stream`) ----
-    void vocode_dev(const float *d_mel, uint32_t T, float *d_wav);
-    void decode_dev(const float *d_hidden, const float *d_style, uint32_t T, float *d_mel);
-    // d_hidden [T][E]; taps are device pointers inside the arena, valid until the next call
+    // every tensor is the row concatenation over the batch: mel [t_rows][M], wav [t_rows * hop], hidden [t_rows][E],
+    // ids / puncts [n_rows], styles [nseg][E]
+    void vocode_dev(const Batch &b, const float *d_mel, float *d_wav);
+    void decode_dev(const Batch &b, const float *d_hidden, const float *d_styles, float *d_mel);
+    // taps are device pointers inside the arena (token rows as in ids), valid until the next call;
+    // n_frames [nseg] is written to d_nframes (outside the arena)
     struct EncoderTaps
     {
         float   *features = nullptr, *logdur = nullptr, *pitch = nullptr, *energy = nullptr;
-        int32_t *pitch_bucket = nullptr, *energy_bucket = nullptr, *n_frames = nullptr;
+        int32_t *pitch_bucket = nullptr, *energy_bucket = nullptr, *cum = nullptr;
     };
-    EncoderTaps encode_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
-                           float *d_hidden);
+    EncoderTaps encode_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles,
+                           float *d_hidden, int32_t *d_nframes);
 
     void reserve(uint32_t max_phonemes, uint32_t max_frames);
+    void reserve_batch(const Batch &b);
+    // largest frame count one segment may have: byte offsets inside a segment are 32-bit in the buffer descriptors
+    uint32_t max_frames_per_utterance() const;
+    int wemb_rows() const { return enc_.wemb_rows; }
+    int pemb_rows() const { return enc_.pemb_rows; }
     // receptive field of the vocoder in mel frames per side (input conv + per stage: transposed-conv taps and the widest
     // residual block, converted from the stage's sample rate), rounded up, + 1
     uint32_t vocoder_halo_frames() const;
@@ -106,12 +135,12 @@ class Model
 
     // graph replay of the vocoder schedule
     bool graph_mode = false;
-    void vocode_dev_graph(const float *d_mel, uint32_t T, float *d_wav);
-    // encoder -> decoder -> vocoder back to back (graph replay keyed by (N, T, buffers) when graph_mode is on)
-    // d_nframes (device, 4 bytes, outside the arena) receives the regulator's frame count: the encoder's tap area is
-    // recycled by the decoder
-    void chain_dev(const int32_t *d_ids, const int32_t *d_puncts, const float *d_style, uint32_t N, uint32_t T,
-                   float *d_hidden, float *d_mel, float *d_wav, int32_t *d_nframes);
+    void vocode_dev_graph(const Batch &b, const float *d_mel, float *d_wav);
+    // encoder -> decoder -> vocoder back to back (graph replay keyed by (capacities, buffers) when graph_mode is on).
+    // h2d_src / h2d_dst / h2d_bytes (optional): an input upload that becomes the first node of the schedule
+    void chain_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles, float *d_hidden,
+                   float *d_mel, float *d_wav, int32_t *d_nframes, const void *h2d_src = nullptr, void *h2d_dst = nullptr,
+                   size_t h2d_bytes = 0);
 
     // profiling (HIP events around every launch while enabled)
     bool profiling = false;
@@ -178,7 +207,7 @@ class Model
     struct Enc
     {
         float *wemb = nullptr, *pemb = nullptr, *posenc = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr;
-        int    posenc_rows = 0;
+        int    posenc_rows = 0, wemb_rows = 0, pemb_rows = 0;
         std::vector<EncLayer> layers;
         VarPred dur, pitch, energy;
     } enc_;
@@ -186,13 +215,13 @@ class Model
     // ---- activations ----
     DeviceArena arena_;
     void  arena_require(size_t bytes);
-    size_t arena_bytes_for(uint32_t N, uint32_t T) const;
+    size_t arena_bytes_for(size_t n_rows, size_t t_rows, int nseg) const;
     void *io_ = nullptr;
     size_t io_cap_ = 0;
 
     // ---- launch helpers ----
-    void conv(const ConvJob *jobs, int n, const char *name, double bytes, double flops);
-    ConvJob job(const ConvW &w, int L) const;
+    void conv(const ConvJob *jobs, int n, const Segs &segs, int rate, const char *name, double bytes, double flops);
+    ConvJob job(const ConvW &w) const;
     void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
     void tock(hipEvent_t e0, const char *name, double bytes, double flops);
     void group_begin();
@@ -219,9 +248,9 @@ class Model
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
     bool force_fuse256_ = false;  // ZV_FUSE256=1: fused kernel for the 256-channel stage at any length (tests: the path
                                   // long / batched utterances take, exercised at sizes the CPU oracle can check)
-    std::vector<VocoderGraph> graphs_;
-    std::vector<ChainGraph> chain_graphs_;
+    std::vector<CapturedGraph> graphs_;
     void drop_graphs();
+    template <typename F> void run_captured(int kind, const Batch &b, const void *const *key, int nkey, F &&enqueue);
 };
 
 }  // namespace zv

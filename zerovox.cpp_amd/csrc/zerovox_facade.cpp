@@ -40,13 +40,13 @@ FS2Encoder::FS2Encoder(weights_t &ctx_w, backend_t backend, uint32_t max_n_phone
 uint32_t FS2Encoder::eval(const int32_t *src_seq_data, const int32_t *puncts_data, const float *style_embed_data,
                           uint32_t num_phonemes, float *x)
 {
-    // The reference graph always encodes max_n_phonemes tokens (no mask, src/fs2encoder.cpp:103-110) and the
-    // regulator walks the first num_phonemes of them (:622).  Its only caller passes num_phonemes ==
-    // max_n_phonemes (src/zerovox.cpp:200), which is the case supported here.
-    if (num_phonemes != max_n_phonemes)
-        throw zv::Error(ZV_ERR_ARG, "FS2Encoder::eval: num_phonemes must equal max_n_phonemes (the graph has no mask)");
+    // The reference graph always encodes max_n_phonemes tokens (no mask, src/fs2encoder.cpp:103-110,598-600: all
+    // max_n_phonemes ids are uploaded) and the regulator walks the first num_phonemes of them (:622).
+    if (num_phonemes > max_n_phonemes)
+        throw zv::Error(ZV_ERR_ARG, "FS2Encoder::eval: num_phonemes exceeds max_n_phonemes");
     uint32_t n_frames = 0;
-    chk(zv_encode(model, src_seq_data, puncts_data, style_embed_data, max_n_phonemes, max_seq_len, x, &n_frames));
+    chk(zv_encode_taps(model, src_seq_data, puncts_data, style_embed_data, max_n_phonemes, num_phonemes, max_seq_len, x,
+                       &n_frames, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     return n_frames;
 }
 
@@ -157,17 +157,16 @@ void ZeroVOXModel::eval(const int32_t *src_seq, const int32_t *puncts, const flo
 
 void ZeroVOXModel::eval(void)
 {
-    // The reference hard-codes one utterance here (src/zerovox.cpp:204-205: 120 phoneme / punctuation ids of a
-    // German sentence) together with a 528-float style vector from its speaker encoder, which is not part of
-    // the repository.  We keep the demo entry point but drive it with a deterministic built-in utterance.
-    int32_t ids[MAX_N_PHONEMES], puncts[MAX_N_PHONEMES];
-    for (int i = 0; i < MAX_N_PHONEMES; i++)
-    {
-        ids[i] = 1 + (i * 37 + 11) % NUM_PHONEMES;
-        puncts[i] = (i % 9 == 8) ? 2 : ((i % 3) ? 1 : 0);
-    }
+    // The reference hard-codes one utterance here (src/zerovox.cpp:204-314: 120 phoneme / punctuation ids of a German
+    // sentence and a 528-float style vector from its speaker encoder); the same data drives this entry point
+    // (zv_demo_utterance).  A checkpoint whose style width differs from 528 gets the first min(E, 528) values, zeros behind.
+    const int32_t *ids = nullptr, *puncts = nullptr;
+    const float *sty = nullptr;
+    uint32_t n = 0, ns = 0;
+    zv_demo_utterance(&ids, &puncts, &sty, &n, &ns);
     std::vector<float> style(hparams.emb_dim + hparams.punct_emb_dim, 0.0f);
-    eval(ids, puncts, style.data(), MAX_N_PHONEMES);
+    for (size_t i = 0; i < style.size() && i < ns; i++) style[i] = sty[i];
+    eval(ids, puncts, style.data(), n);
 }
 
 bool ZeroVOXModel::write_wav_file(const std::string &fname)
