@@ -123,7 +123,7 @@ class Oracle:
         self._chk(self.lib.zvo_decoder(self.ctx, _p(hidden), _p(style), T, _p(mel)))
         return mel
 
-    def encoder(self, geom, ids, puncts, style, T: int) -> dict:
+    def encoder(self, geom, ids, puncts, style, T: int, num_phonemes: Optional[int] = None) -> dict:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         puncts = np.ascontiguousarray(puncts, dtype=np.int32)
         style = np.ascontiguousarray(style, dtype=np.float32)
@@ -139,6 +139,10 @@ class Oracle:
                                        _p(out["pitch"]), _p(out["energy"]), _p(out["pitch_bucket"]),
                                        _p(out["energy_bucket"])))
         out["n_frames"] = int(nf.value)
+        if num_phonemes is not None and num_phonemes < N:
+            # FS2Encoder::eval(num_phonemes < max_n_phonemes): every token is encoded, the regulator walks the first
+            # num_phonemes (reference src/fs2encoder.cpp:622)
+            out["hidden"], out["n_frames"] = self.length_regulator(out["features"][:num_phonemes], out["logdur"][:num_phonemes], T)
         return out
 
     def length_regulator(self, features: np.ndarray, logdur: np.ndarray, T: int):

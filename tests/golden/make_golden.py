@@ -61,6 +61,47 @@ def case(geom_name, T, N, full, tmp="/tmp"):
     os.remove(path)
 
 
+def demo_case(tmp="/tmp"):
+    """ZeroVOXModel::eval() of the reference (src/zerovox.cpp:198-335): its hard-coded utterance (120 phonemes, the
+    528-float style vector) through encoder -> decoder -> vocoder back to back at T = max_seq_len, on the synthetic
+    medium checkpoint.  The utterance comes from the product library's zv_demo_utterance (data extracted from the
+    reference source by scripts/extract_demo_utterance.py)."""
+    from zerovox_cpp_amd import capi
+    g = synth.MEDIUM
+    path = os.path.join(tmp, "golden_medium.gguf")
+    synth.write_checkpoint(path, g, SEED_W)
+    ids, puncts, style = capi.demo_utterance()
+    T = g.max_seq_len
+    r = zvoracle.run_reference_chain(path, ids, puncts, style, T=T)
+    out = dict(geometry="medium", seed_w=SEED_W, T=T, N=len(ids), stride=STRIDE, n_frames=r["n_frames"], logdur=r["logdur"],
+               pitch=r["pitch"], energy=r["energy"], pitch_bucket=r["pitch_bucket"], energy_bucket=r["energy_bucket"],
+               hidden_sha256=sha(r["hidden"]), mel_sha256=sha(r["mel"]), wav_sha256=sha(r["wav"]),
+               features_sha256=sha(r["features"]),
+               wav_samples=r["wav"][::STRIDE].copy(), mel_samples=r["mel"].reshape(-1)[::STRIDE].copy(),
+               wav_rms=float(np.sqrt(np.mean(r["wav"].astype(np.float64) ** 2))))
+    np.savez_compressed(os.path.join(HERE, "demo_medium_T%d.npz" % T), **out)
+    print("demo utterance: frames", r["n_frames"], "wav rms", out["wav_rms"])
+    os.remove(path)
+
+
+def numph_case(tmp="/tmp"):
+    """FS2Encoder::eval with num_phonemes < max_n_phonemes (reference src/fs2encoder.cpp:594-650): the graph encodes all
+    max_n_phonemes tokens, the length regulator walks the first num_phonemes."""
+    g = synth.SMALL
+    path = os.path.join(tmp, "golden_small.gguf")
+    synth.write_checkpoint(path, g, SEED_W)
+    N, num, T = 16, 9, 64
+    ids, puncts, style = synth.encoder_inputs(g, 5, N)
+    e = zvoracle.run_reference(path, T=T, N=N, enc=(ids, puncts, style), E=g.E, num_phonemes=num)
+    full = zvoracle.run_reference(path, T=T, N=N, enc=(ids, puncts, style), E=g.E)
+    assert np.array_equal(e["features"], full["features"]) and e["n_frames"] < full["n_frames"]
+    np.savez_compressed(os.path.join(HERE, "small_T64_N16_num9.npz"), geometry="small", seed_w=SEED_W, T=T, N=N, num=num,
+                        seed_enc=5, hidden=e["hidden"], n_frames=e["n_frames"], logdur=e["logdur"],
+                        features_sha256=sha(e["features"]))
+    print("num_phonemes case: frames", e["n_frames"], "of", full["n_frames"])
+    os.remove(path)
+
+
 def norm_kat():
     src = "/root/reference/utils/norm1dexample.json"
     if not os.path.exists(src):
@@ -83,3 +124,5 @@ if __name__ == "__main__":
     case("medium", 512, 128, full=False)     # configs[2]
     case("medium", 1024, 256, full=False)    # configs[3]: T = 1 024, its longest utterance (256 phonemes)
     norm_kat()
+    demo_case()
+    numph_case()

@@ -910,9 +910,11 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // (k-1)-row halo dominates (MT >= 2: BM >= 64 / 128 / 256 for 128 / 64 / 32 channels)
     // measured (512 frames, batch 1): BM = 64/128/256 rows (MT = 2) beats MT = 4 at every channel count — three
     // to four workgroups per CU hide the staging / epilogue phases better than taller tiles save weight traffic
-    int MT = 2;
-    (void)wgs;
-    if (mt_env == 2 || mt_env == 4) MT = mt_env;
+    // measured (batch of 32 x 1 024 frames): once a launch has many rounds of workgroups the 128-channel stage is
+    // bound by the weight stream from L2 (1 KiB of B fragment per 2 MFMAs per wave at MT = 2) and BM = 128 is 14 % faster;
+    // the 64-channel stage does not care (-1 %).  The tile height never changes an output bit.
+    int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
+    if ((mt_env == 2 || mt_env == 4) && Cp != 256) MT = mt_env;
 #define ZV_PCASE(cp, mt) \
     if (Cp == cp && MT == mt) return launch_pair_cfg<cp, mt>(s, js, njobs, Lmax, Kmax, dmax);
     ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2)

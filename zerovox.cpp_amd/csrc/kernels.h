@@ -37,7 +37,18 @@ struct Segs
     int        max_rows;     // >= rows of every entry (grid sizing), base units
     Seg        one;          // the segment when tab == null
 };
-__host__ __device__ static inline Seg seg_at(const Segs &s, int u) { return s.tab ? s.tab[u] : s.one; }
+__host__ __device__ static inline Seg seg_at(const Segs &s, int u)
+{
+    Seg g = s.tab ? s.tab[u] : s.one;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the table entry is the same for every lane of a workgroup: keep it (and every pointer / buffer descriptor derived
+    // from it) in scalar registers — a descriptor in vector registers costs a waterfall loop per buffer instruction
+    g.row0 = __builtin_amdgcn_readfirstlane(g.row0);
+    g.rows = __builtin_amdgcn_readfirstlane(g.rows);
+    g.aux = __builtin_amdgcn_readfirstlane(g.aux);
+#endif
+    return g;
+}
 static inline Segs segs_single(int rows, int aux = 0)
 {
     Segs s;
