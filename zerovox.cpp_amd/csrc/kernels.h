@@ -211,6 +211,13 @@ hipError_t launch_stats_finalize(hipStream_t s, const double *part, int nblk, in
 hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, const float *stat, int stat_seg, const float *g,
                              const float *b, float *y, int ldy, double *part, int nblk, const Segs &segs);
 
+// y = f16(lrelu(((x - mean) * rstd) * g + b, slope)) for C channels (a multiple of 4): the PRO_NORM_ACT operand written out
+// once (PRO_RAW_F16 consumers).  Channels below Cpart get their statistics from `part` (and store them in `stat`), the
+// others read `stat`.  g / b: per-segment stride gb_seg (0 = shared).
+hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, const double *part, int nblk, int Cpart, float eps,
+                               float *stat, int stat_seg, const float *ga, const float *be, int gb_seg, float slope, void *y,
+                               int ldy, const Segs &segs);
+
 // ---- f32 linear layers: y[n][o] = dot(W[o][:], x[n][:]) + b[o] (ggml_mul_mat on f32 weights) --------
 // `extra` (may be null) is a second per-output addend applied after the bias: (acc + b[o]) + extra[o]
 // (AdaIN: gamma = h[:C] + 1, reference src/stylettsdec.cpp:186-189)

@@ -70,17 +70,9 @@ hipError_t launch_stats_partial(hipStream_t s, const float *x, int ldx, int C, d
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(64) void stats_finalize_kernel(const double *__restrict__ part, int nblk, int C, float eps,
-                                                            float *__restrict__ stat, int stat_seg, int c_off,
-                                                            const Segs segs, int rate)
+// (mean, rstd) of one channel of one segment from its blocks' partial sums, added in block order
+__device__ __forceinline__ float2 stats_from_partials(const double *__restrict__ p, int C, int nb, int L, float eps)
 {
-    const int useg = blockIdx.y;
-    const Seg sg = seg_at(segs, useg);
-    const int L = sg.rows * rate;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C || L <= 0) return;
-    const int nb = (L + 31) >> 5;
-    const double *p = part + ((size_t)useg * nblk * C + c) * 2;
     double s1 = 0.0, s2 = 0.0;
     for (int b = 0; b < nb; b++)
     {
@@ -91,9 +83,22 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const double *__rest
     const double mean = s1 / (double)L;
     double var = s2 / (double)L - mean * mean;
     var = var > 0.0 ? var : 0.0;
+    return make_float2((float)mean, 1.0f / sqrtf((float)var + eps));
+}
+
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const double *__restrict__ part, int nblk, int C, float eps,
+                                                            float *__restrict__ stat, int stat_seg, int c_off,
+                                                            const Segs segs, int rate)
+{
+    const int useg = blockIdx.y;
+    const Seg sg = seg_at(segs, useg);
+    const int L = sg.rows * rate;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C || L <= 0) return;
+    const float2 mr = stats_from_partials(part + ((size_t)useg * nblk * C + c) * 2, C, (L + 31) >> 5, L, eps);
     float *o = stat + (size_t)useg * stat_seg + 2 * (c_off + c);
-    o[0] = (float)mean;
-    o[1] = 1.0f / sqrtf((float)var + eps);
+    o[0] = mr.x;
+    o[1] = mr.y;
 }
 
 hipError_t launch_stats_finalize(hipStream_t s, const double *part, int nblk, int C, float eps, float *stat, int stat_seg,
@@ -161,6 +166,97 @@ hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, cons
     if ((part && nb > nblk) || segs.nseg < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(norm_apply_kernel, dim3((C + 63) / 64, nb, segs.nseg), dim3(256), 0, s, x, ldx, C, stat, stat_seg, g, b, y,
                        ldy, part, nblk, segs);
+    return hipGetLastError();
+}
+
+// The conv operand of an InstanceNorm / AdaIN layer, written once: y = f16(lrelu(((x - mean) * rstd) * g + b, slope)) —
+// the same operations in the same order as the conv kernel's PRO_NORM_ACT prologue, so a conv that reads y (PRO_RAW_F16)
+// gives the bits of a conv that normalises on the fly.  Worth its launch when a conv re-stages its input once per group
+// of output channels (the decoder's 1 056-wide convs: 9 times) — the f32 prologue then runs once instead of 9 times and the
+// staging reads half the bytes.  One workgroup = 64 channels x all rows of one segment; the statistics of channels below
+// Cpart are first finalised from the partial sums (exactly stats_finalize_kernel's arithmetic) and also stored in `stat`.
+__global__ __launch_bounds__(256) void norm_act_f16_kernel(const float *__restrict__ x, int ldx, int C,
+                                                           const double *__restrict__ part, int nblk, int Cpart, float eps,
+                                                           float *__restrict__ stat, int stat_seg,
+                                                           const float *__restrict__ ga, const float *__restrict__ be, int gb_seg,
+                                                           float slope, _Float16 *__restrict__ y, int ldy, const Segs segs)
+{
+    __shared__ float sm[4][64];                  // mean, rstd, gamma, beta
+    const int useg = blockIdx.y;
+    const Seg sg = seg_at(segs, useg);
+    const int L = sg.rows;
+    if (L <= 0) return;
+    const int tid = threadIdx.x;
+    if (tid < 64)
+    {
+        const int c = blockIdx.x * 64 + tid;
+        float2 mr = make_float2(0.f, 0.f);
+        float g = 0.f, b = 0.f;
+        if (c < C)
+        {
+            float *st = stat + (size_t)useg * stat_seg + 2 * c;
+            if (c < Cpart)
+            {
+                mr = stats_from_partials(part + ((size_t)useg * nblk * Cpart + c) * 2, Cpart, (L + 31) >> 5, L, eps);
+                st[0] = mr.x;
+                st[1] = mr.y;
+            }
+            else
+                mr = make_float2(st[0], st[1]);
+            g = ga[(size_t)useg * gb_seg + c];
+            b = be[(size_t)useg * gb_seg + c];
+        }
+        sm[0][tid] = mr.x;
+        sm[1][tid] = mr.y;
+        sm[2][tid] = g;
+        sm[3][tid] = b;
+    }
+    __syncthreads();
+    const int c4 = (tid & 15) * 4, rl = tid >> 4;
+    const int c = blockIdx.x * 64 + c4;
+    if (c >= C) return;                          // C is a multiple of 4
+    const float4 mean = *(const float4 *)&sm[0][c4], rstd = *(const float4 *)&sm[1][c4];
+    const float4 g = *(const float4 *)&sm[2][c4], b = *(const float4 *)&sm[3][c4];
+    const float *xs = x + (size_t)sg.row0 * ldx + c;
+    _Float16 *ys = y + (size_t)sg.row0 * ldy + c;
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    for (int t0 = rl; t0 < L; t0 += 64)
+    {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int t = t0 + 16 * u;
+            v[u] = *(const float4 *)(xs + (size_t)(t < L ? t : L - 1) * ldx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int t = t0 + 16 * u;
+            if (t >= L) continue;
+            float4 r;
+            r.x = ((v[u].x - mean.x) * rstd.x) * g.x + b.x;
+            r.y = ((v[u].y - mean.y) * rstd.y) * g.y + b.y;
+            r.z = ((v[u].z - mean.z) * rstd.z) * g.z + b.z;
+            r.w = ((v[u].w - mean.w) * rstd.w) * g.w + b.w;
+            half4v h;
+            h[0] = (_Float16)(r.x > 0.f ? r.x : r.x * slope);
+            h[1] = (_Float16)(r.y > 0.f ? r.y : r.y * slope);
+            h[2] = (_Float16)(r.z > 0.f ? r.z : r.z * slope);
+            h[3] = (_Float16)(r.w > 0.f ? r.w : r.w * slope);
+            *(half4v *)(ys + (size_t)t * ldy) = h;
+        }
+    }
+}
+
+hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, const double *part, int nblk, int Cpart, float eps,
+                               float *stat, int stat_seg, const float *ga, const float *be, int gb_seg, float slope, void *y,
+                               int ldy, const Segs &segs)
+{
+    if ((C & 3) || (ldx & 3) || (ldy & 3) || segs.nseg < 1 || Cpart > C) return hipErrorInvalidValue;
+    if (Cpart > 0 && (segs.max_rows + 31) / 32 > nblk) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_act_f16_kernel, dim3((C + 63) / 64, segs.nseg), dim3(256), 0, s, x, ldx, C, part, nblk, Cpart, eps, stat,
+                       stat_seg, ga, be, gb_seg, slope, (_Float16 *)y, ldy, segs);
     return hipGetLastError();
 }
 

@@ -573,7 +573,7 @@ size_t Model::arena_bytes_for(size_t n_rows, size_t t_rows, int nseg) const
     const size_t nblk = T / 32 + S;           // >= sum over segments of ceil(T_u / 32) ... sized per segment below
     (void)nblk;
     size_t dec = T * (CAT + 4 * 2 * Ed + 2 * dec_.R) * 4 + S * (size_t)(dec_.fc_out + 8 * CAT + 512) * 4 +
-                 3 * (T / 32 + S) * CAT * 16 + 65536;
+                 3 * (T / 32 + S) * CAT * 16 + T * (CAT + 2 * Ed) * 2 + 65536;
     // encoder
     const size_t Fp = round_up(hp.conv_filter_size, 16);
     size_t enc = N * (Ed * 8 + 3 * Ed + Fp + 1024) * 4 + 65536;
@@ -1022,7 +1022,15 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     float *x0 = arena_.take_n<float>(L * B);
     float *xa = arena_.take_n<float>(L * B);
     float *asr_t = arena_.take_n<float>(L * R);
+    _Float16 *xa16 = arena_.take_n<_Float16>(L * CAT), *t16 = arena_.take_n<_Float16>(L * B);
     const double Ld = (double)L;
+    // Two ways to feed a conv its normalised operand, same bits (tests): (a) the conv normalises while it stages its
+    // input tile (PRO_NORM_ACT) — no extra launch, right for a single utterance where every launch is latency; (b) one
+    // pass writes the f16 operand (launch_norm_act_f16) and the conv copies it (PRO_RAW_F16) — right when launches have
+    // many rounds of workgroups: a 1 056-wide conv stages every input tile 9 times (once per group of 128 output
+    // channels), so (a) repeats the f32 prologue 9 times and reads twice the bytes.
+    const int pre_env = getenv("ZV_DEC_PREPASS") ? atoi(getenv("ZV_DEC_PREPASS")) : -1;      // test / A-B hook, read per call
+    const bool prepass = pre_env >= 0 ? pre_env != 0 : (size_t)bt.t_max * bt.nseg >= 4096;
 
     // D2: all ten AdaIN fc layers at once for every utterance's style vector            (src/stylettsdec.cpp:175-189)
     ZV_LAUNCH("dec_adain_fc", 4.0 * dec_.fc_out * (Ed + 2), 2.0 * S * dec_.fc_out * Ed,
@@ -1034,32 +1042,48 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         ZV_LAUNCH("dec_in_stats", 16.0 * S * nblk * C, 4.0 * S * nblk * C,
                   launch_stats_finalize(stream, part, nblk, C, 1e-5f, stat, ss, c_off, fr, 1));
     };
+    // make `j` read lrelu(norm(x)) with x's statistics still in `part` (channels [0, Cpart)); stores them in `stat`
+    auto norm_input = [&](ConvJob &j, const float *x, int ldx, int C, const double *part, int Cpart, float *stat, const float *g,
+                          const float *b, int gb_seg, _Float16 *op16) {
+        if (prepass)
+        {
+            ZV_LAUNCH("dec_norm_operand", 6.0 * Ld * C, 8.0 * Ld * C,
+                      launch_norm_act_f16(stream, x, ldx, C, part, nblk, Cpart, 1e-5f, stat, ss, g, b, gb_seg, 0.2f, op16, C, fr));
+            j.x0 = op16;
+            j.ldx = C;
+            j.pro = PRO_RAW_F16;
+        }
+        else
+        {
+            finalize(part, Cpart, stat, 0);
+            j.x0 = x;
+            j.ldx = ldx;
+            j.pro = PRO_NORM_ACT;
+            j.pstat = stat;
+            j.pstat_seg = ss;
+            j.pa = g;
+            j.pb = b;
+            j.pab_seg = gb_seg;
+            j.slope = 0.2f;
+        }
+    };
 
     // InstanceNorm statistics of the stage input (it comes from the encoder or the host, not from a conv of ours)
     ZV_LAUNCH("dec_in_stats", 4.0 * Ld * Ed, 3.0 * Ld * Ed, launch_stats_partial(stream, d_hidden, Ed, Ed, part_o, nblk, fr, 1));
-    finalize(part_o, Ed, st_x, 0);
 
     // one residual block: IN/AdaIN -> lrelu -> conv1 -> IN/AdaIN -> lrelu -> conv2 -> (+ shortcut) / sqrt2.
-    // `st_in` holds the statistics of x; the statistics of the block's output land in `st_out` (channels c_off ...)
-    // through the conv epilogue's partial sums when `st_out` is given.  gb_seg: per-segment stride of the affine vectors
-    // (0 for the encode blocks' shared InstanceNorm weights, hs for the decode blocks' AdaIN vectors).
-    auto block = [&](const DecBlk &b, const float *x, int ldx, const float *st_in, const float *g1, const float *b1,
-                     const float *g2, const float *b2, int gb_seg, float *out, int ldo, float *st_out, int c_off) {
+    // The partial sums of x's statistics are in part_o (channels [0, Cpart) of x; the others are final in st_in already);
+    // the block leaves the partial sums of its output in part_o again when want_stats.  gb_seg: per-segment stride of the
+    // affine vectors (0 for the encode blocks' shared InstanceNorm weights, hs for the decode blocks' AdaIN vectors).
+    auto block = [&](const DecBlk &b, const float *x, int ldx, int Cpart, float *st_in, const float *g1, const float *b1,
+                     const float *g2, const float *b2, int gb_seg, float *out, int ldo, bool want_stats) {
         const float *res = x;
         int ldres = ldx;
         ConvJob jj[2];
         int nj = 0;
         {
             ConvJob j = job(b.conv1);
-            j.x0 = x;
-            j.ldx = ldx;
-            j.pro = PRO_NORM_ACT;
-            j.pstat = st_in;
-            j.pstat_seg = ss;
-            j.pa = g1;
-            j.pb = b1;
-            j.pab_seg = gb_seg;
-            j.slope = 0.2f;
+            norm_input(j, x, ldx, b.cin, part_o, Cpart, st_in, g1, b1, gb_seg, xa16);
             j.out = t1;
             j.stat_part = part_t;
             j.stat_nblk = nblk;
@@ -1087,24 +1111,15 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         }
         conv(jj, nj, fr, 1, "dec_conv", bytes, flops);
         const int Cm = b.conv1.Cout;
-        finalize(part_t, Cm, st_t, 0);
         {
             ConvJob j = job(b.conv2);
-            j.x0 = t1;
-            j.ldx = b.conv1.Cout_p;
-            j.pro = PRO_NORM_ACT;
-            j.pstat = st_t;
-            j.pstat_seg = ss;
-            j.pa = g2;
-            j.pb = b2;
-            j.pab_seg = gb_seg;
-            j.slope = 0.2f;
+            norm_input(j, t1, b.conv1.Cout_p, Cm, part_t, Cm, st_t, g2, b2, gb_seg, t16);
             j.res = res;
             j.ldres = ldres;
             j.escale = rsqrt2;
             j.out = out;
             j.ldo = ldo;
-            if (st_out)
+            if (want_stats)
             {
                 j.stat_part = part_o;
                 j.stat_nblk = nblk;
@@ -1112,12 +1127,11 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
             }
             conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Cm, b.cout, 3, true), conv_flops(Ld, Cm, b.cout, 3));
         }
-        if (st_out) finalize(part_o, b.cout, st_out, c_off);
     };
 
     // encode0 / encode1: ResBlk1d with affine InstanceNorm                         (src/stylettsdec.cpp:69-149,373-374)
-    block(dec_.enc[0], d_hidden, Ed, st_x, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, 0, x0, B, st_y, 0);
-    block(dec_.enc[1], x0, B, st_y, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, 0, cat, CAT, st_x, 0);
+    block(dec_.enc[0], d_hidden, Ed, Ed, st_x, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, 0, x0, B, true);
+    block(dec_.enc[1], x0, B, B, st_y, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, 0, cat, CAT, true);
 
     // asr_res = IN_affine(conv1x1(enc_seq) + b) written straight into the concat buffer      (:382-404)
     {
@@ -1132,23 +1146,23 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         finalize(part_t, R, st_a, 0);
         ZV_LAUNCH("dec_norm_apply", 8.0 * Ld * R, 3.0 * Ld * R,
                   launch_norm_apply(stream, asr_t, R, R, st_a, ss, dec_.asr1w, dec_.asr1b, cat + B, CAT, part_t, nblk, fr));
-        finalize(part_t, R, st_x, B);            // statistics of the concat's asr columns: valid for decode0..2
+        finalize(part_t, R, st_x, B);            // statistics of the concat's asr columns: final for decode0..2
     }
 
-    // decode0..4: AdainResBlk1d; blocks 0..2 read cat([x, asr]) and 0,1 write x back into it   (:406-428)
+    // decode0..4: AdainResBlk1d; blocks 0..2 read cat([x, asr]) and 0,1 write x back into it   (:406-428).  The x
+    // columns' statistics arrive as partial sums from the producing conv2, the asr columns' are already in st_x.
     const float *cur = cat;
     int ldc = CAT;
-    const float *st_cur = st_x;
     float *outs[5] = {cat, cat, xa, x0, xa};
     const int ldos[5] = {CAT, CAT, Ed, Ed, Ed};
-    float *sts[5] = {st_x, st_x, st_y, st_x, nullptr};      // decode0/1 refresh the x columns of the concat's statistics
+    const int cparts[5] = {B, B, B, Ed, Ed};
+    float *sts[5] = {st_x, st_x, st_x, st_y, st_y};
     for (int i = 0; i < 5; i++)
     {
         const DecBlk &b = dec_.dec[i];
-        block(b, cur, ldc, st_cur, h + b.g1, h + b.g1 + b.cin, h + b.g2, h + b.g2 + b.cout, hs, outs[i], ldos[i], sts[i], 0);
+        block(b, cur, ldc, cparts[i], sts[i], h + b.g1, h + b.g1 + b.cin, h + b.g2, h + b.g2 + b.cout, hs, outs[i], ldos[i], i < 4);
         cur = outs[i];
         ldc = ldos[i];
-        st_cur = sts[i];
     }
     // to_out: conv1x1 E -> num_mels + b, emitted frame-major                                       (:432-441)
     {
