@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1]/[2] extras (used under rocprofv3)")
+    ap.add_argument("--dump-dir", default=None, help="every rank saves its utterances' waveforms there (tests: union of the shards)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +144,9 @@ def main():
     res = call.results()
     if not all(np.isfinite(w).all() and 0 < nf <= T for (w, nf) in res):
         sys.exit("bench.py: non-finite waveform or bad frame count")
+    if args.dump_dir:
+        np.savez(os.path.join(args.dump_dir, "rank%d.npz" % rank), index=np.arange(lo, hi), n_frames=np.array([nf for _, nf in res]),
+                 **{"wav%d" % u: w for u, (w, _) in zip(range(lo, hi), res)})
 
     # ---- roofline of the dominant kernel family, same batch workload: live HIP-event timing, eager launches ----
     roofline, kernels = None, []

@@ -145,3 +145,42 @@ def test_oracle_conv_against_independent_torch_fp32(k, dil, ic, oc, L):
     ref = torch.nn.functional.conv1d(x16, torch.from_numpy(w.astype(np.float32)), torch.from_numpy(b), padding=pad, dilation=dil)[0].numpy()
     assert got.shape == ref.shape == (oc, L)
     assert np.max(np.abs(got - ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(ref))))
+
+
+def test_oracle_reproduces_reference_demo_utterance(ckpt):
+    """ZeroVOXModel::eval() of the reference (its hard-coded 120-phoneme utterance + 528-float style vector, the three
+    stages back to back at T = max_seq_len, src/zerovox.cpp:198-335) on the synthetic medium checkpoint: the oracle
+    chain reproduces every stage of the compiled reference bit for bit.  The utterance data is served by the product
+    library (zv_demo_utterance), which needs no GPU."""
+    from zerovox_cpp_amd import capi
+    from oracle import zvoracle
+    z = np.load(os.path.join(GOLD, "demo_medium_T1500.npz"))
+    path, g, tensors = ckpt("medium", int(z["seed_w"]))
+    ids, puncts, style = capi.demo_utterance()
+    assert len(ids) == 120 == int(z["N"]) and style.shape == (528,) and g.E == 528
+    assert ids[0] == 69 and ids[-1] == 87 and puncts[-1] == 3            # first / last entries of the reference's literals
+    T, s = int(z["T"]), int(z["stride"])
+    assert T == g.max_seq_len
+    orc = zvoracle.Oracle(tensors)
+    e = orc.encoder(g, ids, puncts, style, T)
+    assert e["n_frames"] == int(z["n_frames"])
+    for k in ("logdur", "energy", "pitch_bucket", "energy_bucket"):
+        assert np.array_equal(e[k], z[k]), k
+    assert sha(e["features"]) == str(z["features_sha256"]) and sha(e["hidden"]) == str(z["hidden_sha256"])
+    mel = orc.decoder(e["hidden"], style)
+    assert np.array_equal(mel.reshape(-1)[::s], z["mel_samples"]) and sha(mel) == str(z["mel_sha256"])
+    wav = orc.vocoder(mel)
+    assert np.array_equal(wav[::s], z["wav_samples"]) and sha(wav) == str(z["wav_sha256"])
+
+
+def test_oracle_reproduces_reference_num_phonemes_below_max(ckpt):
+    """FS2Encoder::eval(num_phonemes < max_n_phonemes): all tokens are encoded, the regulator walks the first num
+    (reference src/fs2encoder.cpp:594-650)"""
+    from zerovox_cpp_amd import synth
+    from oracle import zvoracle
+    z = np.load(os.path.join(GOLD, "small_T64_N16_num9.npz"))
+    path, g, tensors = ckpt("small", int(z["seed_w"]))
+    ids, puncts, style = synth.encoder_inputs(g, int(z["seed_enc"]), int(z["N"]))
+    e = zvoracle.Oracle(tensors).encoder(g, ids, puncts, style, int(z["T"]), num_phonemes=int(z["num"]))
+    assert e["n_frames"] == int(z["n_frames"]) and np.array_equal(e["hidden"], z["hidden"])
+    assert np.array_equal(e["logdur"], z["logdur"]) and sha(e["features"]) == str(z["features_sha256"])
