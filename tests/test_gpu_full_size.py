@@ -193,7 +193,8 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
     path, g, tensors = ckpt("medium")
     mel = synth.vocoder_mel(g, tensors, 51, 384)
     outs = {}
-    for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"})):
+    for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"}),
+                      ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"})):
         os.environ.update(env)
         try:
             m = capi.Model(path, 0)

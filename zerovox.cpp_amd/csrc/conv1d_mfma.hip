@@ -150,6 +150,14 @@ __device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int 
                         x.z = ((x.z + v1[u].z) + v2[u].z) * sc;
                         x.w = ((x.w + v1[u].w) + v2[u].w) * sc;
                     }
+                    else if constexpr (pro == PRO_SCALE_ACT)
+                    {
+                        const float sc = J.pscale;
+                        x.x = x.x * sc;
+                        x.y = x.y * sc;
+                        x.z = x.z * sc;
+                        x.w = x.w * sc;
+                    }
                     else if constexpr (pro == PRO_NORM_ACT)
                     {
                         const float4 st0 = *(const float4 *)(J.pstat + 2 * c);       // mean,rstd,mean,rstd
@@ -199,6 +207,7 @@ __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *sme
         case PRO_ACT: stage_tile_p<U, PRO_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         case PRO_NORM_ACT: stage_tile_p<U, PRO_NORM_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         case PRO_MELNORM: stage_tile_p<U, PRO_MELNORM, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        case PRO_SCALE_ACT: stage_tile_p<U, PRO_SCALE_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         default: stage_tile_p<U, PRO_SUM3_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
     }
 }
@@ -734,17 +743,18 @@ __device__ __forceinline__ void stage_act_buf(__amdgpu_buffer_rsrc_t rsrc, char 
     }
 }
 
-template <int CP, int MT>
+// MERGE: one workgroup runs the SAME time tile of all the launch's jobs (the MRF branches of a stage) one after the other
+// and stores only (out_0 + out_1) + out_2 — the sum the next layer starts with (reference src/hifigan.cpp:300-315) — so the
+// branch outputs of a stage's last dilation pair never reach HBM and the consumer reads one tensor instead of three.  The
+// tile height is that of the job with the most taps (a few rows of extra halo for the others).
+template <int CP, int MT, bool MERGE>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 {
     constexpr int NT = (CP == 256) ? 2 : 1;            // output tiles of 32 channels per wave
     constexpr int WN = CP / 32 / NT, WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    const PairJob &P = jobs.j[blockIdx.z];
-    const int K = P.K, dil = P.dil;
-    const int h2 = (K - 1) / 2, h1 = h2 * dil;
-    const int TM = BM - 2 * h2;
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[blockIdx.z].K - 1);
     // workgroup -> (segment, time tile): every segment gets the tile count of the longest one, tiles past a segment's
     // end exit; the XCD map runs over the whole (segment, tile) range, so an XCD works on neighbouring tiles of
     // neighbouring utterances
@@ -756,8 +766,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int L = sg.rows * jobs.rate;
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
+    floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
+    for (int jb = MERGE ? 0 : (int)blockIdx.z; jb < (MERGE ? jobs.njobs : (int)blockIdx.z + 1); jb++)
+    {
+    const PairJob &P = jobs.j[jb];
+    const int K = P.K, dil = P.dil;
+    const int h2 = (K - 1) / 2, h1 = h2 * dil;
     const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
+    if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the LDS tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -849,17 +866,35 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+            if constexpr (MERGE)
+            {
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[r]), rs_out, voff,
-                                                      (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+                for (int r = 0; r < 16; r++)
+                {
+                    const float v = (acc[mt][nt][r] + bias) + resv[r];
+                    msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
+                }
+                if (jb == jobs.njobs - 1)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(msum[mt][nt][r]), rs_out, voff,
+                                                              (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+            }
+            else
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[r]), rs_out, voff,
+                                                          (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+            }
         }
+    }
     }
 }
 
 bool pair_supported(int Cp) { return Cp == 32 || Cp == 64 || Cp == 128 || Cp == 256; }
 
-template <int CP, int MT>
+template <int CP, int MT, bool MERGE>
 static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
 {
     constexpr int WNc = (CP == 256) ? 4 : CP / 32;
@@ -867,10 +902,10 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     const int TMmin = BM - (Kmax - 1);
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
-    dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
+    dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);      // multiple of 8: zv_xcd_tile
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil
     const size_t lds = (size_t)(BM + (Kmax + 4) * dmax) * (CP * 2 + 16);
-    auto kern = resblock_pair_kernel<CP, MT>;
+    auto kern = resblock_pair_kernel<CP, MT, MERGE>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -880,7 +915,7 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     return hipGetLastError();
 }
 
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
@@ -888,6 +923,8 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     PairJobs js;
     js.segs = segs;
     js.rate = rate;
+    js.njobs = njobs;
+    js.merge_out = merge_out;
     const int Lmax = segs.max_rows * rate;
     int Kmax = 0, dmax = 0;
     for (int i = 0; i < njobs; i++)
@@ -915,8 +952,11 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // the 64-channel stage does not care (-1 %).  The tile height never changes an output bit.
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
     if ((mt_env == 2 || mt_env == 4) && Cp != 256) MT = mt_env;
-#define ZV_PCASE(cp, mt) \
-    if (Cp == cp && MT == mt) return launch_pair_cfg<cp, mt>(s, js, njobs, Lmax, Kmax, dmax);
+    js.kmax = Kmax;
+#define ZV_PCASE(cp, mt)                                                                                 \
+    if (Cp == cp && MT == mt)                                                                            \
+        return merge_out ? launch_pair_cfg<cp, mt, true>(s, js, njobs, Lmax, Kmax, dmax)                 \
+                         : launch_pair_cfg<cp, mt, false>(s, js, njobs, Lmax, Kmax, dmax);
     ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2)
 #undef ZV_PCASE
     return hipErrorInvalidValue;
@@ -1166,6 +1206,13 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const OutConvArgs a)
                 v.y = ((v.y + b.y) + d.y) * a.pscale;
                 v.z = ((v.z + b.z) + d.z) * a.pscale;
                 v.w = ((v.w + b.w) + d.w) * a.pscale;
+            }
+            else
+            {   // x0 already is the branches' sum (merged last pair of the stage)
+                v.x = v.x * a.pscale;
+                v.y = v.y * a.pscale;
+                v.z = v.z * a.pscale;
+                v.w = v.w * a.pscale;
             }
             h[0] = (_Float16)lrelu(v.x, a.slope);
             h[1] = (_Float16)lrelu(v.y, a.slope);

@@ -75,7 +75,8 @@ enum ConvPrologue : int
     PRO_ACT = 1,          // f16(lrelu(x, slope))            (slope 1 = identity, 0 = relu)
     PRO_NORM_ACT = 2,     // f16(lrelu(((x - mean_c) * rstd_c) * g_c + b_c, slope))   InstanceNorm/AdaIN
     PRO_MELNORM = 3,      // f16((x - a_c) / b_c)            (src/hifigan.cpp:242-243)
-    PRO_SUM3_ACT = 4      // f16(lrelu(((x0 + x1) + x2) * pscale, slope))   MRF mean (src/hifigan.cpp:300-315)
+    PRO_SUM3_ACT = 4,     // f16(lrelu(((x0 + x1) + x2) * pscale, slope))   MRF mean (src/hifigan.cpp:300-315)
+    PRO_SCALE_ACT = 5     // f16(lrelu(x * pscale, slope))                  MRF mean whose sum the producer already formed
 };
 
 struct ConvJob
@@ -149,13 +150,17 @@ struct PairJobs
     PairJob j[PAIR_MAX_JOBS];
     Segs    segs;
     int     rate;
+    int     njobs, kmax;
+    float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
 };
 // true when a ResBlock with Cp (padded) channels can run on the fused kernel
 bool       pair_supported(int Cp);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
+// merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
+// stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);
 
 // ---- a whole HiFi-GAN residual block (reference src/hifigan.cpp:74-185: the loop over all dilations) in ONE launch:
 // a workgroup keeps a 256-row f32 tile of y in LDS, runs the n_dil fused pairs on it and writes the centre rows once.

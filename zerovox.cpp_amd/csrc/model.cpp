@@ -145,6 +145,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
     no_triple_ = getenv("ZV_NO_TRIPLE") && atoi(getenv("ZV_NO_TRIPLE")) != 0;
     force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
+    no_merge_ = getenv("ZV_NO_MERGE") && atoi(getenv("ZV_NO_MERGE")) != 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
     lanes_[0].stream = stream;
@@ -751,6 +752,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
 
     const float third = (float)(1.0 / (float)voc_.n_rb);            // src/hifigan.cpp:315
     const float *prev_y[3] = {nullptr, nullptr, nullptr};
+    const float *prev_merged = nullptr;          // the previous stage stored (y0 + y1) + y2 instead of the three branches
     for (int i = 0; i < voc_.n_up; i++)
     {
         const int s = voc_.scales[i];
@@ -771,6 +773,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
             ConvJob j = job(up);
             j.slope = 0.1f;
             if (i == 0) { j.x0 = c0; j.pro = PRO_ACT; }
+            else if (prev_merged) { j.x0 = prev_merged; j.pro = PRO_SCALE_ACT; j.pscale = third; }
             else { j.x0 = prev_y[0]; j.x1 = prev_y[1]; j.x2 = prev_y[2]; j.pro = PRO_SUM3_ACT; j.pscale = third; }
             j.out = ub;
             // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
@@ -792,6 +795,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
         const bool enough_rows = Cp != 256 || force_fuse256_ || (Lbatch / 54) * 3 >= 2L * n_cu;
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
+        const float *merged_sum = nullptr;
         group_begin();
         // narrow stages: the whole residual block (all dilations) of the three branches in ONE launch, y tile kept
         // in registers between the dilation pairs (launch_triple)
@@ -881,7 +885,17 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
                 b2 += conv_bytes((double)L, C, C, rp.c2.K, true);
                 f2 += conv_flops((double)L, C, C, rp.c2.K);
             }
-            if (fused)
+            // the last pair of the stage: the three branches' outputs are only ever used summed (MRF, :300-315), so the
+            // workgroups run all three branches of a tile and store the sum alone
+            const bool merge = fused && !no_merge_ && d == voc_.n_dil - 1;
+            if (merge)
+            {
+                float *ms = (pj[0].out != pj[0].y && pj[0].out != pj[1].y && pj[0].out != pj[2].y) ? pj[0].out : nullptr;
+                if (!ms) fail(ZV_ERR_DEVICE, "internal: no free buffer for the merged MRF sum");
+                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate, ms));
+                merged_sum = ms;
+            }
+            else if (fused)
                 ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate));
             else
             {
@@ -892,14 +906,15 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
         group_end("voc_resblock_conv");
         for (int jb = 0; jb < 3; jb++) y[jb] = const_cast<float *>(ycur[jb]);
         for (int jb = 0; jb < 3; jb++) prev_y[jb] = y[jb];
+        prev_merged = merged_sum;
     }
 
     // V3: (sum of branches)/3 -> leaky_relu(0.01) -> conv k7 (C -> 1) + b -> tanh          (:315-345)
     {
         OutConvArgs a;
-        a.x0 = prev_y[0];
-        a.x1 = prev_y[1];
-        a.x2 = prev_y[2];
+        a.x0 = prev_merged ? prev_merged : prev_y[0];
+        a.x1 = prev_merged ? nullptr : prev_y[1];
+        a.x2 = prev_merged ? nullptr : prev_y[2];
         a.ldx = round_up(C, 16);
         a.L = 0;
         a.C = C;

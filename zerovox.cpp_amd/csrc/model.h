@@ -246,6 +246,7 @@ class Model
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
+    bool no_merge_ = false;       // ZV_NO_MERGE=1: the last dilation pair of a stage stores its three branch outputs instead of their sum (A/B, tests)
     bool force_fuse256_ = false;  // ZV_FUSE256=1: fused kernel for the 256-channel stage at any length (tests: the path
                                   // long / batched utterances take, exercised at sizes the CPU oracle can check)
     std::vector<CapturedGraph> graphs_;
