@@ -215,18 +215,20 @@ __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *sme
 // ---- compute: S = K * nkc MFMA steps over one staged chunk.  A fragments are double-buffered in registers
 // (the ds_reads of step s+1 are in flight while the MFMAs of step s run), B fragments come from L2 through a
 // 4-deep register ring.
-template <int MT, bool SWAP = false>
-__device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT][1], const char *abase, int RS, int dil, const half8 *wp,
-                                           int K, int nkc)
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT][NT], const char *abase, int RS, int dil, const half8 *wp,
+                                           size_t wseg, int K, int nkc)
 {
     // Branch-free, 4 steps per iteration with static register slots so that hipcc can count its waits: the B
     // fragment consumed in slot u was requested four steps earlier (s_waitcnt vmcnt(3)), the A fragments one step
     // earlier.  Steps S..round_up(S,4)-1 do not exist: they run with B = 0 (adds nothing) on a clamped A address.
     const int S = K * nkc;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    half8 b[4];
+    half8 b[4][NT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) b[u] = wp[(size_t)((u < S) ? u : S - 1) * 64];
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b[u][nt] = wp[nt * wseg + (size_t)((u < S) ? u : S - 1) * 64];
     half8 a[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) a[mt] = *(const half8 *)(abase + mt * 32 * RS);
@@ -242,18 +244,17 @@ __device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT][1], const char *a
             half8 an[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) an[mt] = *(const half8 *)(ap + mt * 32 * RS);
-            const half8 bu = (s0 + u < S) ? b[u] : zero8;
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int nt = 0; nt < NT; nt++)
             {
-                // SWAP: weights as the A operand -> D[oc][time] (4 consecutive channels per lane register quad)
-                if constexpr (SWAP)
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bu, a[mt], acc[mt][0], 0, 0, 0);
-                else
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bu, acc[mt][0], 0, 0, 0);
+                const half8 bu = (s0 + u < S) ? b[u][nt] : zero8;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bu, acc[mt][nt], 0, 0, 0);
             }
             const int sn = s0 + u + 4;
-            b[u] = wp[(size_t)((sn < S) ? sn : S - 1) * 64];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b[u][nt] = wp[nt * wseg + (size_t)((sn < S) ? sn : S - 1) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) a[mt] = an[mt];
         }
@@ -446,7 +447,9 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
     if ((threadIdx.x & 63) < 32) *(double2 *)dst = make_double2(s1, s2);
 }
 
-template <int MT, int WN>
+// Each wave owns (32*MT) rows x (32*NT) output channels: NT = 2 halves the LDS reads per MFMA (an A fragment feeds two
+// MFMAs) and lets a workgroup cover 256 output channels, so a wide conv stages its input half as often.
+template <int MT, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
@@ -471,8 +474,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
     const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
     const int nicb = Cin_p >> 4;
     const int ntiles = (Cout_p + 31) >> 5;
-    const int nt = blockIdx.y * WN + wn;
-    const bool n_ok = nt < ntiles;
+    const int nt0 = (blockIdx.y * WN + wn) * NT;
+    const bool n_ok = nt0 < ntiles;
+    // a wave whose second tile does not exist computes the last tile twice and stores it once
+    const int ntl = nt0 + NT <= ntiles ? nt0 : (ntiles - NT > 0 ? ntiles - NT : 0);
     const int rows = BM + (K - 1) * dil;
     const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
 
@@ -491,11 +496,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
         S.pscale = J.pscale;
     }
 
-    floatx16 acc[MT][1];
+    floatx16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][0][r] = 0.f;
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
 
@@ -507,81 +514,88 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
         __syncthreads();
         if (n_ok && !(J.dbg & 2))
         {
-            const half8 *wp = (const half8 *)J.w + ((size_t)nt * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
+            const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
+            const size_t wseg = (size_t)K * nicb * 64;             // half8 units between consecutive output tiles
             // full chunks of 256 / 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there
             // and the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
             if (ck == 256 && J.ck == 256)
-                mfma_taps<256, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
+                mfma_taps<256, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
             else if (ck == 128 && J.ck == 128)
-                mfma_taps<128, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
+                mfma_taps<128, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
             else if (ck == 64 && J.ck == 64)
-                mfma_taps<64, MT, 1, false>(acc, abase, dil * RS, wp, 0, K);
+                mfma_taps<64, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
             else
-                mfma_chunk<MT>(acc, abase, RS, dil, wp, K, ck >> 4);
+                mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
         }
     }
 
     // ---------------- epilogue ----------------
     if (!n_ok || (J.dbg & 4)) return;
-    const int oc = nt * 32 + (lane & 31);
-    if (oc >= Cout_p) return;
-    const float bias = J.bias ? J.bias[oc] : 0.f;
     const float escale = J.escale;
     const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
     const bool has_res = J.res != nullptr;
     const float *res = has_res ? J.res + row0 * J.ldres : nullptr;
     const size_t out0 = row0 * J.ldo;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int n = 0; n < NT; n++)
     {
-        float resv[16];
-        if (has_res)
-        {
+        const int nt = ntl + n;
+        if (nt < nt0) continue;                       // the duplicate of a clamped pair
+        const int oc = nt * 32 + (lane & 31);
+        if (oc >= Cout_p) continue;
+        const float bias = J.bias ? J.bias[oc] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
+        for (int mt = 0; mt < MT; mt++)
+        {
+            float resv[16];
+            if (has_res)
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
+                {
+                    const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+                }
+            }
+            float outv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
             {
                 const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+                float v = acc[mt][n][r] + bias;
+                if (has_res) v = v + resv[r];
+                v = v * escale;
+                if (J.eact) v = lrelu(v, J.oslope);
+                outv[r] = v;
+                if (t < L)
+                {
+                    if (J.out_f16)
+                        ((_Float16 *)J.out)[out0 + (size_t)t * J.ldo + oc] = (_Float16)v;
+                    else
+                        ((float *)J.out)[out0 + (size_t)t * J.ldo + oc] = v;
+                }
             }
-        }
-        float outv[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-            float v = acc[mt][0][r] + bias;
-            if (has_res) v = v + resv[r];
-            v = v * escale;
-            if (J.eact) v = lrelu(v, J.oslope);
-            outv[r] = v;
-            if (t < L)
+            if (J.stat_part && oc < J.stat_C)
             {
-                if (J.out_f16)
-                    ((_Float16 *)J.out)[out0 + (size_t)t * J.ldo + oc] = (_Float16)v;
-                else
-                    ((float *)J.out)[out0 + (size_t)t * J.ldo + oc] = v;
+                const int blk = (m0 >> 5) + wm * MT + mt;                  // 32-row block of the segment
+                if (blk * 32 < L)
+                    tile_stats_store(outv, tbase + mt * 32, L, J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc) * 2);
             }
-        }
-        if (J.stat_part && oc < J.stat_C)
-        {
-            const int blk = (m0 >> 5) + wm * MT + mt;                  // 32-row block of the segment
-            if (blk * 32 < L)
-                tile_stats_store(outv, tbase + mt * 32, L, J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc) * 2);
         }
     }
 }
 
-template <int MT, int WN>
+template <int MT, int WN, int NT>
 static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int halo, int ck, int dmax_)
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     const int ntiles = (Cout_p + 31) / 32;
     jobs.tps = (Lmax + BM - 1) / BM;
-    dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN - 1) / WN, njobs);
+    dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN * NT - 1) / (WN * NT), njobs);
     const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_mfma_kernel<MT, WN>;
+    auto kern = conv1d_mfma_kernel<MT, WN, NT>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -615,25 +629,31 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
     for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     const int Cout_p = jobs[0].Cout_p;
     const int ntiles = (Cout_p + 31) / 32;
-    const int WN = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+    // three output tiles already take four waves (one idles): the input tile is staged once instead of twice
+    const int WN = ntiles >= 3 ? 4 : (ntiles >= 2 ? 2 : 1);
     // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups; the tile
-    // height never changes an output bit: every output element is one accumulator chain over (chunk, tap, channel)
-    auto wgs = [&](int MT) {
+    // shape never changes an output bit: every output element is one accumulator chain over (chunk, tap, channel)
+    auto wgs = [&](int MT, int NT) {
         const int BM = 32 * MT * (4 / WN);
-        return (long)((Lmax + BM - 1) / BM) * segs.nseg * ((ntiles + WN - 1) / WN) * njobs;
+        return (long)((Lmax + BM - 1) / BM) * segs.nseg * ((ntiles + WN * NT - 1) / (WN * NT)) * njobs;
     };
     int MT = 4;
-    while (MT > 1 && wgs(MT) < 2L * n_cu) MT >>= 1;
+    while (MT > 1 && wgs(MT, 1) < 2L * n_cu) MT >>= 1;
     while (MT > 1 && (size_t)(32 * MT * (4 / WN) + halo + dmax) * (ck * 2 + 16) > 80 * 1024) MT >>= 1;   // keep >= 2 workgroups per CU in LDS
     {   // measurement hook (environment table): ZV_CONV_MT=<minimum MT>
         static const char *e_mt = getenv("ZV_CONV_MT");
         if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
     }
-#define ZV_CASE(mt, wn) \
-    if (MT == mt && WN == wn) return launch_cfg<mt, wn>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
-    ZV_CASE(4, 4) ZV_CASE(2, 4) ZV_CASE(1, 4)
-    ZV_CASE(4, 2) ZV_CASE(2, 2) ZV_CASE(1, 2)
-    ZV_CASE(4, 1) ZV_CASE(2, 1) ZV_CASE(1, 1)
+    // two output tiles per wave once a conv is wide and the launch still has rounds of workgroups to spare
+    static const int nt_env = getenv("ZV_CONV_NT") ? atoi(getenv("ZV_CONV_NT")) : 0;
+    int NT = (WN == 4 && ntiles >= 8 && MT >= 2 && wgs(MT, 2) >= 4L * n_cu) ? 2 : 1;
+    if (nt_env == 1 || (nt_env == 2 && WN == 4 && ntiles >= 2 && MT >= 2)) NT = nt_env;
+    if (NT == 2 && MT == 4) MT = 2;        // 64 x 64 per wave: the 128 x 64 shape does not fit 256 registers
+#define ZV_CASE(mt, wn, nt) \
+    if (MT == mt && WN == wn && NT == nt) return launch_cfg<mt, wn, nt>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
+    ZV_CASE(4, 4, 1) ZV_CASE(2, 4, 1) ZV_CASE(1, 4, 1) ZV_CASE(2, 4, 2)
+    ZV_CASE(4, 2, 1) ZV_CASE(2, 2, 1) ZV_CASE(1, 2, 1)
+    ZV_CASE(4, 1, 1) ZV_CASE(2, 1, 1) ZV_CASE(1, 1, 1)
 #undef ZV_CASE
     return hipErrorInvalidValue;
 }
