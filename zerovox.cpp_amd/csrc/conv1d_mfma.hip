@@ -261,18 +261,21 @@ __device__ __forceinline__ void mfma_chunk(floatx16 (&acc)[MT][NT], const char *
     }
 }
 
-template <int MT, int NT, bool SWAP>
+// ZERO: the first step of a contraction — the accumulator operand is the constant 0 (an inline constant of the
+// instruction: no 16 x MT x NT register moves to clear the accumulators first)
+template <int MT, int NT, bool SWAP, bool ZERO = false>
 __device__ __forceinline__ void mfma_step(floatx16 (&acc)[MT][NT], const half8 (&a)[MT], const half8 (&b)[NT])
 {
+    const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
         {
             if constexpr (SWAP)      // weights as the A operand -> D[oc][time]
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nt], a[mt], ZERO ? z : acc[mt][nt], 0, 0, 0);
             else
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], ZERO ? z : acc[mt][nt], 0, 0, 0);
         }
 }
 
@@ -352,6 +355,9 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 // behind the read: LDS latency exposed on every step); a fence per step pins the reads where they are written, and two
 // steps (>= 4 MFMAs at MT = 2) cover the ds_read_b128 latency.  Used by the fused ResBlock kernels, which have the
 // registers to spare; in the generic kernel's widest instantiations the fences cost more registers than they gain.
+// The accumulators need no clearing before the call: the first step starts them from the constant 0.  The contraction is
+// walked in bodies of 8 steps; CP = 64 with K = 3 mod 4 taps leaves half a body, every other supported shape a whole
+// number (pair_shape_ok).
 template <int CP, int MT, int NT, bool SWAP, int DEPTH = 2>
 __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
 {
@@ -376,6 +382,26 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
         _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 8][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
     }
 #define ZV_STEP2(u, bset) ZV_LOAD_A2((u) + DEPTH) mfma_step<MT, NT, SWAP>(acc, a[(u) % 8], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
+#define ZV_STEP2Z(u, bset) ZV_LOAD_A2((u) + DEPTH) mfma_step<MT, NT, SWAP, true>(acc, a[(u) % 8], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
+#define ZV_BODY(FIRSTSTEP)                                                                                       \
+    {                                                                                                            \
+        const char *tb[4], *tbn[4];                                                                              \
+        tb[0] = ap;                                                                                              \
+        _Pragma("unroll") for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;                   \
+        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + TPB * dilRS; /* next body */  \
+        tbn[0] = apn;                                                                                            \
+        _Pragma("unroll") for (int x = 1; x < 4; x++) tbn[x] = (x < TPB) ? apn + x * dilRS : apn;                \
+        _Pragma("unroll") for (int u = 0; u < 4; u++)                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b1[u][nt] = wq[nt * wseg + u * 64];                \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        FIRSTSTEP(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)                                         \
+        _Pragma("unroll") for (int u = 0; u < 4; u++)                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + (4 + u) * 64];          \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        ZV_STEP2(4, b1) ZV_STEP2(5, b1) ZV_STEP2(6, b1) ZV_STEP2(7, b1)                                          \
+        ap = apn;                                                                                                \
+        wq += 8 * 64;                                                                                            \
+    }
     {
         const char *tb[4], *tbn[4];
         tb[0] = ap;
@@ -391,38 +417,21 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
         if constexpr (DEPTH > 5) ZV_LOAD_A2(5)
         if constexpr (DEPTH > 6) ZV_LOAD_A2(6)
     }
-    for (int ib = 0; ib < nb; ib++)
     {
-        const char *tb[4], *tbn[4];
-        tb[0] = ap;
-#pragma unroll
-        for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
-        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + TPB * dilRS;   // next body
-        tbn[0] = apn;
-#pragma unroll
-        for (int x = 1; x < 4; x++) tbn[x] = (x < TPB) ? apn + x * dilRS : apn;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b1[u][nt] = wq[nt * wseg + u * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        ZV_STEP2(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + (4 + u) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        ZV_STEP2(4, b1) ZV_STEP2(5, b1) ZV_STEP2(6, b1) ZV_STEP2(7, b1)
-        ap = apn;
-        wq += 8 * 64;
+        const int ib = 0;
+        ZV_BODY(ZV_STEP2Z)
     }
-    if (nsb & 1)                                 // odd sub-block count (CP = 64): one more tap on b0
-    {
-        const char *tb[4] = {ap, ap, ap, ap};
-        const char *tbn[4] = {ap, ap, ap, ap};
-        (void)tbn;
-        ZV_STEP2(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)
-    }
+    for (int ib = 1; ib < nb; ib++) ZV_BODY(ZV_STEP2)
+    if constexpr (CP == 64)
+        if (nsb & 1)                             // odd sub-block count (K = 3 mod 4 taps): one more tap on b0
+        {
+            const char *tb[4] = {ap, ap, ap, ap};
+            const char *tbn[4] = {ap, ap, ap, ap};
+            (void)tbn;
+            ZV_STEP2(0, b0) ZV_STEP2(1, b0) ZV_STEP2(2, b0) ZV_STEP2(3, b0)
+        }
+#undef ZV_BODY
+#undef ZV_STEP2Z
 #undef ZV_STEP2
 #undef ZV_LOAD_A2
 #undef ZV_A_ADDR2
@@ -811,12 +820,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
     floatx16 acc[MT][NT];
+    if (P.dbg & 2)          // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
 #pragma unroll
-    for (int i = 0; i < MT; i++)
+        for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int n = 0; n < NT; n++)
+            for (int n = 0; n < NT; n++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
     if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K);
@@ -826,6 +836,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     {
         const int hh = lane >> 5;
         const float sl = P.slope;
+        // only the first and the last tile of a segment hold rows outside [0, L): interior tiles skip the masking
+        const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
         {
@@ -838,7 +850,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
             {
                 const int i = wm * 32 * MT + mt * 32 + (lane & 31);
                 const int t = t0 - h2 + i;
-                const bool in = t >= 0 && t < L;
+                const bool in = !edge || (t >= 0 && t < L);
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                 {
@@ -848,8 +860,11 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
                     h[2] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 2] + bq[q].z, sl);
                     h[3] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 3] + bq[q].w, sl);
                     uint2 pk = *(uint2 *)&h;
-                    pk.x = in ? pk.x : 0u;
-                    pk.y = in ? pk.y : 0u;
+                    if (edge)
+                    {
+                        pk.x = in ? pk.x : 0u;
+                        pk.y = in ? pk.y : 0u;
+                    }
                     *(uint2 *)(smem + i * RS + (ocb + 8 * q + 4 * hh) * 2) = pk;
                 }
             }
@@ -858,12 +873,6 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     __syncthreads();
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
     if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
@@ -912,7 +921,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     }
 }
 
-bool pair_supported(int Cp) { return Cp == 32 || Cp == 64 || Cp == 128 || Cp == 256; }
+// the MFMA loop of the fused kernels walks whole 8-step bodies (CP = 64: also half a body at the end) and at least one
+bool pair_supported(int Cp, int K)
+{
+    if (!(Cp == 32 || Cp == 64 || Cp == 128 || Cp == 256) || K < 1 || (K & 1) == 0) return false;
+    const int nsb = (K * (Cp / 16) + 3) >> 2;
+    return nsb >= 2 && (Cp == 64 || (nsb & 1) == 0);
+}
 
 template <int CP, int MT, bool MERGE>
 static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
@@ -1025,6 +1040,8 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
     const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
     float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
     const int XM = h2 * dmax;
+    // only the tiles at a segment's ends hold rows outside [0, L): the others skip every range mask
+    const bool edge = t0 - H < 0 || t0 - H + R > L;
     const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1068,10 +1085,11 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
         // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
         floatx16 acc[MT][1];
+        if (P.dbg & 2)      // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2))
             mfma_taps_deep<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K);
         __syncthreads();                       // every wave is done reading X: the region becomes XT
@@ -1085,7 +1103,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
             {
                 const int i = wave * 32 * MT + mt * 32 + (lane & 31);
                 const int t = t0 - H + i;
-                const bool in = t >= 0 && t < L;
+                const bool in = !edge || (t >= 0 && t < L);
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                 {
@@ -1095,8 +1113,11 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
                     h[2] = (_Float16)lrelu_max(acc[mt][0][4 * q + 2] + bq[q].z, sl);
                     h[3] = (_Float16)lrelu_max(acc[mt][0][4 * q + 3] + bq[q].w, sl);
                     uint2 pk = *(uint2 *)&h;
-                    pk.x = in ? pk.x : 0u;
-                    pk.y = in ? pk.y : 0u;
+                    if (edge)
+                    {
+                        pk.x = in ? pk.x : 0u;
+                        pk.y = in ? pk.y : 0u;
+                    }
                     *(uint2 *)(smem + (XM + i) * RS + (8 * q + 4 * hh) * 2) = pk;
                 }
             }
@@ -1104,23 +1125,29 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
         __syncthreads();
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2))
             mfma_taps_deep<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K);
         {
             const float bias = P.b2[d][col];
+            if (edge)
+            {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+                for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                {
-                    const int t = t0 - H + irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = (acc[mt][0][r] + bias) + yreg[mt][r];
-                    yreg[mt][r] = (t >= 0 && t < L) ? v : 0.f;
-                }
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const int t = t0 - H + irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                        const float v = (acc[mt][0][r] + bias) + yreg[mt][r];
+                        yreg[mt][r] = (t >= 0 && t < L) ? v : 0.f;
+                    }
+            }
+            else
+            {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) yreg[mt][r] = (acc[mt][0][r] + bias) + yreg[mt][r];
+            }
         }
     }
 
@@ -1141,7 +1168,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
 bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 {
-    if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || (K & 1) == 0) return false;
+    if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || !pair_supported(Cp, K)) return false;
     int sumd = 0;
     for (int d = 0; d < n_dil; d++) sumd += dil[d];
     return 256 - (K - 1) * (sumd + n_dil) >= 96;          // at least 3/8 of the tile's rows are output

@@ -153,8 +153,8 @@ struct PairJobs
     int     njobs, kmax;
     float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
 };
-// true when a ResBlock with Cp (padded) channels can run on the fused kernel
-bool       pair_supported(int Cp);
+// true when a ResBlock conv pair with Cp (padded) channels and K taps can run on the fused kernel
+bool       pair_supported(int Cp, int K);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);

@@ -233,7 +233,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
                 snprintf(nb, sizeof(nb), "_meldec.blocks.%d.convs2.%d.1.b", n, d);
                 rp.c2 = load_conv(g, nm, nb, C);
                 if (rp.c1.Cout != C || rp.c2.Cout != C) fail(ZV_ERR_SHAPE, "residual block %d: channel mismatch", n);
-                if (pair_supported(rp.c1.Cout_p) && rp.c1.K == rp.c2.K)
+                if (rp.c1.K == rp.c2.K && pair_supported(rp.c1.Cout_p, rp.c1.K))
                 {
                     std::vector<uint16_t> pk(pair_weight_halfs(rp.c1.Cout_p, rp.c1.K));
                     void **dst[2] = {&rp.p1, &rp.p2};
