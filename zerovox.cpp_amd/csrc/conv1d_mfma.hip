@@ -358,19 +358,27 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 // The accumulators need no clearing before the call: the first step starts them from the constant 0.  The contraction is
 // walked in bodies of 8 steps; CP = 64 with K = 3 mod 4 taps leaves half a body, every other supported shape a whole
 // number (pair_shape_ok).
+// the first four weight fragments of a contraction: requested by the caller ahead of a phase that does not need them (the
+// staging wait, the xt pack) so that the MFMA loop does not start with an exposed L2 round trip
+template <int NT>
+__device__ __forceinline__ void deep_preload_b(half8 (&b0)[4][NT], const half8 *wq, size_t wseg)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + u * 64];
+}
+
 template <int CP, int MT, int NT, bool SWAP, int DEPTH = 2>
-__device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
+__device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K,
+                                               half8 (&b0)[4][NT])
 {
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;
     constexpr bool HALF = NKC == 16;
     const int nsb = (K * NKC + 3) >> 2;
     const int nb = nsb >> 1;
-    half8 b0[4][NT], b1[4][NT];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b0[u][nt] = wq[nt * wseg + u * 64];
+    half8 b1[4][NT];
     wq += 4 * 64;
     static_assert(DEPTH >= 1 && DEPTH <= 7, "A fragments travel DEPTH steps ahead through a ring of 8 register sets");
     half8 a[8][MT];
@@ -735,6 +743,20 @@ __device__ __forceinline__ float lrelu_max(float x, float s)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
+// stamps the clock at its phase boundaries into a buffer of its own (cdna_hip_programming.md §7, in-kernel stamps)
+#ifdef ZV_STAMPS
+constexpr int ZV_STAMP_WGS = 1 << 17, ZV_STAMP_N = 12;
+__device__ unsigned long long zv_stamp_buf[(size_t)ZV_STAMP_WGS * ZV_STAMP_N];
+#define ZV_STAMP(k)                                                                                   \
+    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)                                    \
+    {                                                                                                 \
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + (k)] = __builtin_amdgcn_s_memrealtime();         \
+    }
+#else
+#define ZV_STAMP(k)
+#endif
+
 // Stage f16(lrelu(y)) rows through a buffer descriptor: rows outside [0, L) are out of the descriptor's range and
 // read as 0 (= the conv's zero padding, lrelu(0) = 0) with no per-row predicate; CP is a power of two so the
 // row / column split of the flat index is a shift and a mask.
@@ -795,6 +817,16 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int L = sg.rows * jobs.rate;
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.z;
+    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
+    {
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 9] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 10] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    ZV_STAMP(0)
     floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
     for (int jb = MERGE ? 0 : (int)blockIdx.z; jb < (MERGE ? jobs.njobs : (int)blockIdx.z + 1); jb++)
     {
@@ -815,8 +847,16 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
-    if (!(P.dbg & 1)) stage_act_buf<ZV_STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+    // every staging load of the tile is in flight before the first one is consumed (one HBM round trip instead of one
+    // per batch of four: measured 6.7 of a workgroup's 20.5 us at 64 channels)
+    // (the merged variant holds the running sum of the branches: it keeps the short batches and its occupancy)
+    constexpr int STAGE_U = MERGE ? ZV_STAGE_U : ((CP == 32) ? 10 : (CP == 64 ? 12 : 8));
+    half8 bw[4][NT];
+    deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
+    if (!(P.dbg & 1)) stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+    ZV_STAMP(1)
     __syncthreads();
+    ZV_STAMP(2)
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
     floatx16 acc[MT][NT];
@@ -829,8 +869,11 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
                 for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw);
+    deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
+    ZV_STAMP(3)
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
+    ZV_STAMP(4)
 
     // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
     {
@@ -871,13 +914,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
         }
     }
     __syncthreads();
+    ZV_STAMP(5)
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
     // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
     // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
+    ZV_STAMP(6)
     if (P.dbg & 4) return;
     const int nrows = (L - t0 < TM) ? (L - t0) : TM;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
@@ -894,7 +939,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
             float resv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                resv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+                resv[r] = (P.dbg & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+            if (P.dbg & 16) continue;
             if constexpr (MERGE)
             {
 #pragma unroll
@@ -918,8 +964,19 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
             }
         }
     }
+#ifdef ZV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ZV_STAMP(7)
     }
 }
+
+#ifdef ZV_STAMPS
+extern "C" int zv_debug_read_stamps(unsigned long long *out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zv_stamp_buf), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // the MFMA loop of the fused kernels walks whole 8-step bodies (CP = 64: also half a body at the end) and at least one
 bool pair_supported(int Cp, int K)
@@ -960,6 +1017,9 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     js.rate = rate;
     js.njobs = njobs;
     js.merge_out = merge_out;
+#ifdef ZV_STAMPS
+    js.stamp = getenv("ZV_STAMP_CP") && atoi(getenv("ZV_STAMP_CP")) == jobs[0].Cp && !merge_out;
+#endif
     const int Lmax = segs.max_rows * rate;
     int Kmax = 0, dmax = 0;
     for (int i = 0; i < njobs; i++)
@@ -1068,6 +1128,8 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
     const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
     const float sl = P.slope;
+    half8 bw[4][1];
+    deep_preload_b<1>(bw, (const half8 *)P.w1[0] + lane, wseg);            // the first conv's fragments travel under the tile load
     for (int d = 0; d < nd; d++)
     {
         const int dil = P.dil[d], h1 = h2 * dil;
@@ -1091,7 +1153,8 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2))
-            mfma_taps_deep<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K);
+            mfma_taps_deep<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K, bw);
+        deep_preload_b<1>(bw, (const half8 *)P.w2[d] + lane, wseg);                 // under the xt pack
         __syncthreads();                       // every wave is done reading X: the region becomes XT
         {
             const int hh = lane >> 5;
@@ -1126,7 +1189,8 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
         if (!(P.dbg & 2))
-            mfma_taps_deep<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K);
+            mfma_taps_deep<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K, bw);
+        if (d + 1 < nd) deep_preload_b<1>(bw, (const half8 *)P.w1[d + 1] + lane, wseg);      // under the epilogue and the next X write
         {
             const float bias = P.b2[d][col];
             if (edge)

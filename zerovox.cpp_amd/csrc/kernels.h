@@ -151,6 +151,9 @@ struct PairJobs
     Segs    segs;
     int     rate;
     int     njobs, kmax;
+#ifdef ZV_STAMPS
+    int     stamp;               // diagnostic build: this launch writes phase stamps
+#endif
     float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
 };
 // true when a ResBlock conv pair with Cp (padded) channels and K taps can run on the fused kernel
