@@ -74,11 +74,18 @@ hipError_t launch_stats_partial(hipStream_t s, const float *x, int ldx, int C, d
 __device__ __forceinline__ float2 stats_from_partials(const double *__restrict__ p, int C, int nb, int L, float eps)
 {
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; b++)
+    for (int b0 = 0; b0 < nb; b0 += 8)          // eight loads in flight, added in block order
     {
-        const double2 v = *(const double2 *)(p + (size_t)b * C * 2);
-        s1 += v.x;
-        s2 += v.y;
+        double2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = *(const double2 *)(p + (size_t)(b0 + i < nb ? b0 + i : nb - 1) * C * 2);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (b0 + i < nb)
+            {
+                s1 += v[i].x;
+                s2 += v[i].y;
+            }
     }
     const double mean = s1 / (double)L;
     double var = s2 / (double)L - mean * mean;
@@ -267,6 +274,7 @@ hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, co
 // A workgroup of 4 waves owns 64 rows x 128 outputs: wave w the outputs [32w, 32w + 32) of both 32-row halves, so a
 // W operand feeds two MFMAs.  Lane l holds A[row l&31][k + (l>>5)] / B[k + (l>>5)][col l&31].
 // `extra[o]` is added after the bias (AdaIN: gamma = h[:C] + 1, src/stylettsdec.cpp:186-189).
+template <int RT>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restrict__ x, int ldx, int in,
                                                           const float *__restrict__ W, const float *__restrict__ b, int out,
                                                           float *__restrict__ y, int ldy, const float *__restrict__ extra,
@@ -274,12 +282,12 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
 {
     // 32-wide k-chunks of both operands go through LDS: global rows are read as coalesced 128-B segments, the MFMA
     // operand (one f32 per lane, rows across lanes) comes back from LDS with a 33-float row stride (conflict-free)
-    __shared__ float Xs[64][33];
+    __shared__ float Xs[32 * RT][33];
     __shared__ float Ws[128][33];
     const int useg = blockIdx.y / tps;
     const Seg sg = seg_at(segs, useg);
     const int n = sg.rows;
-    const int n0 = (blockIdx.y - useg * tps) * 64;
+    const int n0 = (blockIdx.y - useg * tps) * 32 * RT;
     if (n0 >= n) return;
     const float *xs = x + (size_t)sg.row0 * ldx;
     float *ys = y + (size_t)sg.row0 * ldy;
@@ -289,10 +297,10 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
     floatx16m acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.f;
-    float4 xv[2], wv[4];
+    float4 xv[RT], wv[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < RT; u++)
         {
             const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
             const bool kin = k0 + c < in;                      // `in` is a multiple of 4: a float4 is all in or all out
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
     {
         __syncthreads();                                       // previous chunk fully consumed
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < RT; u++)
         {
             const int idx = tid + u * 256, r = idx >> 3, c = (idx & 7) * 4;
             Xs[r][c] = xv[u].x; Xs[r][c + 1] = xv[u].y; Xs[r][c + 2] = xv[u].z; Xs[r][c + 3] = xv[u].w;
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
         {
             const float wk = Ws[wave * 32 + i][k + kk];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[i][k + kk], wk, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[32 + i][k + kk], wk, acc1, 0, 0, 0);
+            if constexpr (RT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[32 + i][k + kk], wk, acc1, 0, 0, 0);
         }
     }
     // D: col = lane&31 (output), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (token)
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
     const float bias = b ? b[col] : 0.f;
     const float ex = extra ? extra[col] : 0.f;
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++)
+    for (int hf = 0; hf < RT; hf++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
@@ -358,9 +366,21 @@ hipError_t launch_linear(hipStream_t s, const float *x, int ldx, int in, const f
                          int ldy, const float *extra, const Segs &segs)
 {
     if ((in & 3) || (ldx & 3) || segs.nseg < 1) return hipErrorInvalidValue;          // float4 row loads
-    const int tps = (segs.max_rows + 63) / 64;
-    hipLaunchKernelGGL(linear_mfma_kernel, dim3((out + 127) / 128, tps * segs.nseg), dim3(256), 0, s, x, ldx, in, W, b, out, y, ldy,
-                       extra, segs, tps);
+    // 64-row workgroups (a W operand feeds two MFMAs) once they fill the chip, 32-row ones for short inputs; the shape
+    // never changes a bit: every output element is one k-ordered chain
+    const long wg64 = (long)((segs.max_rows + 63) / 64) * segs.nseg * ((out + 127) / 128);
+    if (wg64 >= 256)
+    {
+        const int tps = (segs.max_rows + 63) / 64;
+        hipLaunchKernelGGL(linear_mfma_kernel<2>, dim3((out + 127) / 128, tps * segs.nseg), dim3(256), 0, s, x, ldx, in, W, b, out, y,
+                           ldy, extra, segs, tps);
+    }
+    else
+    {
+        const int tps = (segs.max_rows + 31) / 32;
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((out + 127) / 128, tps * segs.nseg), dim3(256), 0, s, x, ldx, in, W, b, out, y,
+                           ldy, extra, segs, tps);
+    }
     return hipGetLastError();
 }
 
@@ -488,6 +508,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
         redm[part][qi] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(redm[0][qi], redm[1][qi]), fmaxf(redm[2][qi], redm[3][qi]));
+        // the sum of the exponentials: four interleaved partial sums (key mod 4), each in key order, then
+        // (p0 + p1) + (p2 + p3) — the scalar kernel below adds in exactly this order, so the two kernels give the same bits
         double sum = 0.0;
         for (int key = part; key < n; key += 4)
         {
@@ -550,8 +572,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     }
 }
 
-// The same operation with scalar fma chains: one block per (query, head).  Fallback for shapes outside the matrix-core
-// kernel's limits (head width not a multiple of 4 or above 288, more keys than fit its LDS score tile).
+// The same operation with scalar fma chains: one block per (query, head) — the same bits as the matrix-core kernel (every
+// dot product is the same k-ordered fma chain, the softmax sum is associated the same way).  Used where that kernel does
+// not fit (head width not a multiple of 4 or above 288, more keys than its LDS score tile holds) and for a single short
+// utterance, where (queries x heads) blocks fill the chip and a handful of 64-query workgroups does not.
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                         const float *__restrict__ v, int ld, int dk, float inv_temp,
                                                         float *__restrict__ o, int ldo, const Segs segs)
@@ -585,17 +609,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     if (lane == 0) redf[wv] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    double sum = 0.0;
-    for (int ik = tid; ik < n; ik += 256)
-    {
-        const float e = expf(p[ik] - mx);
-        p[ik] = e;
-        sum += (double)e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) redd[wv] = sum;
+    for (int ik = tid; ik < n; ik += 256) p[ik] = expf(p[ik] - mx);
     __syncthreads();
-    const float inv = (float)(1.0 / (redd[0] + redd[1] + redd[2] + redd[3]));
+    if (tid < 4)            // the association of attention_mfma_kernel: four interleaved partial sums in key order
+    {
+        double sum = 0.0;
+        for (int ik = tid; ik < n; ik += 4) sum += (double)p[ik];
+        redd[tid] = sum;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / ((redd[0] + redd[1]) + (redd[2] + redd[3])));
     for (int ik = tid; ik < n; ik += 256) p[ik] = p[ik] * inv;
     __syncthreads();
     for (int d = tid; d < dk; d += 256)
@@ -615,7 +638,10 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
     const int KSTR = dk | 1;
     const size_t lds_mfma = ((size_t)64 * KSTR + 1 + (size_t)((n + 31) & ~31) * 64) * sizeof(float);
     static const bool force_scalar = getenv("ZV_ATT_SCALAR") && atoi(getenv("ZV_ATT_SCALAR")) != 0;     // test hook
-    if (!force_scalar && (dk & 3) == 0 && dk <= 2 * ATT_NS_MAX && (ld & 3) == 0 && lds_mfma <= (size_t)ATT_LDS_MAX)
+    static const bool force_mfma = getenv("ZV_ATT_MFMA") && atoi(getenv("ZV_ATT_MFMA")) != 0;               // test hook
+    const long wgs_mfma = (long)((n + 63) / 64) * H * segs.nseg;
+    if (!force_scalar && (dk & 3) == 0 && dk <= 2 * ATT_NS_MAX && (ld & 3) == 0 && lds_mfma <= (size_t)ATT_LDS_MAX &&
+        (wgs_mfma >= 48 || force_mfma))
     {
         auto kern = attention_mfma_kernel;
         if (lds_mfma > 48 * 1024)
