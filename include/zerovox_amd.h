@@ -160,6 +160,18 @@ zv_status zv_profile_begin(zv_model *m);
 /* stops profiling, copies up to cap entries, returns the entry count in *n */
 zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint32_t *n);
 
+/* ---- one layer at a time (tests) — the counterpart of the reference's tensor_dbg (src/utils.cpp:19-44): runs ONE layer of
+ * the production schedule on a caller-supplied input, so a per-layer comparison against the reference semantics does not
+ * compound.  x [rows][cin] and out [rows][cout] are host, time-major, unpadded; rows are rows at the layer's own rate.
+ *   ZV_LAYER_VOC_RESBLOCK  index n = stage * num_resblocks + branch: HiFiGANResidualBlock n (src/hifigan.cpp:74-185), fused
+ *                          kernels; rows must be a multiple of the stage's samples per frame
+ *   ZV_LAYER_ENC_FFT       index l: FFTBlock l = attention sublayer + conv FFN (src/fs2encoder.cpp:71-140,174-228)
+ *   ZV_LAYER_DEC_BLOCK     index 0,1: ResBlk1d encode.{0,1}; 2..6: AdainResBlk1d decode.{0..4} with `style`
+ *                          (src/stylettsdec.cpp:69-149,242-304); cin as the reference (decode.0..2 take the 2E+64 concat)
+ *   ZV_LAYER_VAR_PRED      index 0 duration / 1 pitch / 2 energy: VariancePredictor (src/fs2encoder.cpp:386-440), out [rows] */
+typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLOCK = 2, ZV_LAYER_VAR_PRED = 3 } zv_layer_kind;
+zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out);
+
 /* ---- GGUF inspection without a device (loader half of the boundary; used by the CPU test-suite) ----
  * Parses the file exactly as zv_model_load does and reports the counts; *max_seq_len receives the
  * `<arch>.max_seq_len` KV.  tensor_index >= 0 additionally returns that tensor's name (<= 63 chars + NUL),

@@ -922,3 +922,55 @@ int zvo_encoder(zvo_ctx *c, const zvo_encoder_params *p, const int32_t *ids, con
     free(x); free(y); free(ld); free(pp); free(ep); free(pb); free(eb);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* One layer at a time, for teacher-forced per-layer parity tests (the counterpart of the reference's
+ * tensor_dbg, src/utils.cpp:19-44: the GPU runs the same layer on the same input, so nothing compounds).
+ * All inputs / outputs here are time-major [rows][channels] like the stage boundaries.           */
+
+int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int cols, const float *style, int E, int H,
+              const int *ksz, float *out)
+{
+    apply_threads(c);
+    int rc = 0;
+    if (kind == ZVO_LAYER_VOC_RESBLOCK)                /* HiFiGANResidualBlock `index` (src/hifigan.cpp:74-185): [L][C] -> [L][C] */
+    {
+        const int dils[3] = {1, 3, 5};
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *yc = (float *)malloc((size_t)rows * cols * 4);
+        transpose(x, rows, cols, xc);
+        rc = resblock_cf(c, xc, rows, cols, index, dils, 3, yc);
+        if (!rc) transpose(yc, cols, rows, out);
+        free(xc); free(yc);
+    }
+    else if (kind == ZVO_LAYER_ENC_FFT)                /* FFTBlock `index` (src/fs2encoder.cpp:71-140,174-228): [N][E] -> [N][E] */
+    {
+        float *y = (float *)malloc((size_t)rows * cols * 4);
+        rc = mha(c, x, rows, cols, index, H, y);
+        if (!rc) rc = ffn(c, y, rows, cols, index, ksz, out);
+        free(y);
+    }
+    else if (kind == ZVO_LAYER_DEC_BLOCK)              /* 0,1: ResBlk1d encode.{0,1}; 2..6: AdainResBlk1d decode.{0..4}: [T][cin] -> [T][cout] */
+    {
+        const zvo_tensor *a0w = get(c, "_mel_decoder.asr_res.0.w");
+        if (!a0w) return -1;
+        const int Ed = (int)a0w->ne[1], R = (int)a0w->ne[2], B = 2 * Ed, CAT = B + R;
+        const int dims[7][2] = {{Ed, B}, {B, B}, {CAT, B}, {CAT, B}, {CAT, Ed}, {Ed, Ed}, {Ed, Ed}};
+        if (index < 0 || index > 6 || cols != dims[index][0]) return fail("decoder block %d wants %d channels", index, index >= 0 && index <= 6 ? dims[index][0] : -1);
+        const int co = dims[index][1];
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *yc = (float *)malloc((size_t)rows * co * 4);
+        transpose(x, rows, cols, xc);
+        if (index < 2) rc = resblk1d(c, xc, rows, index, cols, co, yc);
+        else rc = adainresblk1d(c, xc, rows, style, E, index - 2, cols, co, yc);
+        if (!rc) transpose(yc, co, rows, out);
+        free(xc); free(yc);
+    }
+    else if (kind == ZVO_LAYER_VAR_PRED)               /* VariancePredictor 0 duration / 1 pitch / 2 energy: [N][E] -> [N] */
+    {
+        const char *pf[3] = {"_pe._var_adapt.duration_predictor", "_pe._var_adapt.pitch_predictor", "_pe._var_adapt.engy_pred"};
+        if (index < 0 || index > 2) return fail("predictor %d", index);
+        rc = variance_predictor(c, x, rows, cols, pf[index], ksz[0], out);
+    }
+    else
+        return fail("unknown layer kind %d", kind);
+    return rc;
+}

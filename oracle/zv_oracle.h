@@ -81,6 +81,12 @@ int zvo_conv1d(zvo_ctx *c, const float *x, int L, int IC, const uint16_t *w, int
 /* ggml_norm over the last (contiguous) axis, eps inside the sqrt (ggml-cpu.c:6880-6929) */
 void zvo_norm_rows(const float *x, int rows, int n, float eps, float *y);
 
+/* ---- one layer at a time (teacher-forced per-layer parity): x [rows][cols] time-major -> out time-major.
+ * style / E: AdaIN style vector (decoder blocks 2..6); H: heads, ksz: FFN kernel sizes (encoder) or {vp_kernel} */
+enum { ZVO_LAYER_VOC_RESBLOCK = 0, ZVO_LAYER_ENC_FFT = 1, ZVO_LAYER_DEC_BLOCK = 2, ZVO_LAYER_VAR_PRED = 3 };
+int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int cols, const float *style, int E, int H,
+              const int *ksz, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ def _load(path: str):
     lib.zvo_conv1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p]
     lib.zvo_norm_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.zvo_layer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                              C.POINTER(C.c_int), C.c_void_p]
     return lib
 
 
@@ -164,6 +166,19 @@ class Oracle:
         out = np.empty((OC, OL), np.float32)
         b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
         self._chk(self.lib.zvo_conv1d(self.ctx, _p(x_cf), L, IC, _p(w), OC, K, pad, dil, _p(b), _p(out)))
+        return out
+
+    LAYER_VOC_RESBLOCK, LAYER_ENC_FFT, LAYER_DEC_BLOCK, LAYER_VAR_PRED = 0, 1, 2, 3
+
+    def layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None, heads: int = 2, ksz=(9, 1)) -> np.ndarray:
+        """one layer of the reference semantics on a given input (time-major [rows][cols]): HiFi-GAN residual block,
+        FFT block, decoder residual block, variance predictor (out_cols = 0 -> a vector of rows values)"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        rows, cols = x.shape
+        out = np.empty((rows, out_cols) if out_cols else (rows,), np.float32)
+        st = None if style is None else np.ascontiguousarray(style, dtype=np.float32)
+        k = (C.c_int * 2)(*(list(ksz) + [1])[:2])
+        self._chk(self.lib.zvo_layer(self.ctx, kind, index, _p(x), rows, cols, _p(st), 0 if st is None else len(st), heads, k, _p(out)))
         return out
 
     def norm_rows(self, x: np.ndarray, eps: float = 1e-5) -> np.ndarray:

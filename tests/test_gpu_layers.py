@@ -1,0 +1,117 @@
+"""GPU: one layer at a time.  zv_debug_layer runs ONE layer of the production schedule (the fused kernels, the same
+launch configurations) on a given input; the oracle's zvo_layer runs the reference semantics of the same layer on the same
+input (the counterpart of the reference's tensor_dbg, src/utils.cpp:19-44).  Nothing compounds from layer to layer, so
+these gates are far tighter than the stage-level ones: the only differences are f32 summation order and, inside a layer
+with several convs, the occasional f16 re-rounding flip that the order causes — measured against the oracle's own
+re-association noise on the same layer (AVX2 lane order vs sequential f32)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+_M = {}
+
+
+@pytest.fixture(scope="module")
+def env(ckpt):
+    from zerovox_cpp_amd import capi
+    from oracle import zvoracle
+    if "m" not in _M:
+        path, g, tensors = ckpt("medium")
+        _M.update(m=capi.Model(path, 0), g=g, t=tensors, o=zvoracle.Oracle(tensors))
+    yield _M["m"], _M["g"], _M["t"], _M["o"]
+
+
+def teardown_module(module):
+    if "m" in _M:
+        _M["m"].close()
+        _M.clear()
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+
+
+def _check(name, got, ref, alt, rel_gate, floor_mult=2.0):
+    """got: GPU, ref: oracle (ggml AVX2 order), alt: oracle (sequential f32).  rel = rms(err) / rms(signal)."""
+    sig = _rms(ref)
+    err, floor = _rms(got - ref) / sig, _rms(alt - ref) / sig
+    mx = float(np.max(np.abs(got - ref))) / sig
+    print(f"{name:28s} rel rms err {err:.2e} (oracle self-noise {floor:.2e}), max {mx:.2e}, signal rms {sig:.3f}")
+    assert np.isfinite(got).all()
+    assert err <= max(floor_mult * floor, 3e-7), name          # no worse than the reference's own re-association noise
+    assert err <= rel_gate, name
+
+
+def _oracle_pair(o, *args, **kw):
+    from oracle import zvoracle
+    o.set_order(zvoracle.ORDER_GGML_AVX2)
+    ref = o.layer(*args, **kw)
+    o.set_order(zvoracle.ORDER_SEQ_F32)
+    alt = o.layer(*args, **kw)
+    o.set_order(zvoracle.ORDER_GGML_AVX2)
+    return ref, alt
+
+
+@pytest.mark.parametrize("block", list(range(12)))
+def test_every_hifigan_residual_block(env, block):
+    """all 12 residual blocks (4 stages x 3 kernel sizes), each = 3 dilation pairs of 2 convs through the fused pair /
+    whole-block kernels, 32 frames at the stage's rate"""
+    m, g, t, o = env
+    stage = block // 3
+    C, rate = m.voc_channels(stage), m.voc_rate(stage)
+    x = (0.5 * np.random.default_rng(100 + block).standard_normal((32 * rate, C))).astype(np.float32)
+    got = m.debug_layer(m.LAYER_VOC_RESBLOCK, block, x, C)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_RESBLOCK, block, x, C)
+    _check(f"hifigan block {block} (C={C})", got, ref, alt, 2e-4)
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2, 3])
+def test_every_encoder_fft_block(env, layer):
+    """attention sublayer (f32 QKV / attention / fc / add + LayerNorm) + conv FFN (k9 / k1 with the f16 ReLU operand)"""
+    m, g, t, o = env
+    x = np.random.default_rng(200 + layer).standard_normal((96, g.E)).astype(np.float32)
+    got = m.debug_layer(m.LAYER_ENC_FFT, layer, x, g.E)
+    ref, alt = _oracle_pair(o, o.LAYER_ENC_FFT, layer, x, g.E, heads=g.encoder_head, ksz=g.conv_kernel_size)
+    _check(f"encoder FFT block {layer}", got, ref, alt, 1e-4)
+
+
+@pytest.mark.parametrize("block", list(range(7)))
+def test_every_decoder_residual_block(env, block):
+    """ResBlk1d (affine InstanceNorm) x 2 and AdainResBlk1d x 5, each: norm -> lrelu -> conv -> norm -> lrelu -> conv
+    (+ learned 1x1 shortcut) / sqrt 2, statistics from the conv epilogues' partial sums"""
+    m, g, t, o = env
+    E, R = g.E, g.residual_dim
+    cin = [E, 2 * E, 2 * E + R, 2 * E + R, 2 * E + R, E, E][block]
+    cout = [2 * E, 2 * E, 2 * E, 2 * E, E, E, E][block]
+    T = 96
+    # distinct frames (InstanceNorm over near-identical frames only measures rounding of the statistics)
+    x = (1.2 * np.random.default_rng(300 + block).standard_normal((T, cin))).astype(np.float32)
+    style = (0.05 * np.random.default_rng(7).standard_normal(E)).astype(np.float32)
+    for pre in ("0", "1"):                       # both ways of feeding the convs their normalised operand
+        os.environ["ZV_DEC_PREPASS"] = pre
+        try:
+            got = m.debug_layer(m.LAYER_DEC_BLOCK, block, x, cout, style=style)
+        finally:
+            del os.environ["ZV_DEC_PREPASS"]
+        ref, alt = _oracle_pair(o, o.LAYER_DEC_BLOCK, block, x, cout, style=style)
+        _check(f"decoder block {block} ({cin}->{cout}) prepass={pre}", got, ref, alt, 3e-4)
+
+
+@pytest.mark.parametrize("p", [0, 1, 2])
+def test_every_variance_predictor(env, p):
+    m, g, t, o = env
+    x = np.random.default_rng(400 + p).standard_normal((80, g.E)).astype(np.float32)
+    got = m.debug_layer(m.LAYER_VAR_PRED, p, x, 0)
+    ref, alt = _oracle_pair(o, o.LAYER_VAR_PRED, p, x, 0, ksz=(g.vp_kernel_size,))
+    _check(f"variance predictor {p}", got, ref, alt, 1e-4)
+
+
+def test_unknown_layers_are_errors(env):
+    from zerovox_cpp_amd import capi
+    m, g, t, o = env
+    x = np.zeros((32, g.E), np.float32)
+    for kind, idx in ((m.LAYER_ENC_FFT, 99), (m.LAYER_DEC_BLOCK, 7), (9, 0)):
+        with pytest.raises(capi.ZvError):
+            m.debug_layer(kind, idx, x, g.E)

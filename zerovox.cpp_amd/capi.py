@@ -19,7 +19,7 @@ SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
-    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance",
+    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance", "zv_debug_layer",
 ]
 
 
@@ -68,6 +68,7 @@ def load_library(path: Optional[str] = None):
     lib.zv_model_reserve.argtypes = [vp, u32, u32]
     lib.zv_encode.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
     lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
+    lib.zv_debug_layer.argtypes = [vp, C.c_int, C.c_int, fp, u32, fp, fp]
     lib.zv_max_frames.argtypes = [vp]
     lib.zv_max_frames.restype = u32
     lib.zv_demo_utterance.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
@@ -164,6 +165,25 @@ class Model:
         mel = np.empty((T, self.hp.audio_num_mels), np.float32)
         self._chk(self.lib.zv_decode(self.h, _ptr(hidden), _ptr(style), T, _ptr(mel)))
         return mel
+
+    LAYER_VOC_RESBLOCK, LAYER_ENC_FFT, LAYER_DEC_BLOCK, LAYER_VAR_PRED = 0, 1, 2, 3
+
+    def debug_layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None) -> np.ndarray:
+        """zv_debug_layer: one layer of the production schedule on the given input (time-major [rows][cin])"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((x.shape[0], out_cols) if out_cols else (x.shape[0],), np.float32)
+        st = None if style is None else np.ascontiguousarray(style, dtype=np.float32)
+        self._chk(self.lib.zv_debug_layer(self.h, kind, index, _ptr(x), x.shape[0], _ptr(st), _ptr(out)))
+        return out
+
+    def voc_rate(self, stage: int) -> int:
+        r = 1
+        for i in range(stage + 1):
+            r *= self.hp.voc_upsample_scales[i]
+        return r
+
+    def voc_channels(self, stage: int) -> int:
+        return self.hp.voc_channels >> (stage + 1)
 
     def max_frames(self) -> int:
         return int(self.lib.zv_max_frames(self.h))

@@ -417,6 +417,68 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
     });
 }
 
+// ---- one layer at a time (tests: teacher-forced per-layer parity) -------------------------------------------------
+
+zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out)
+{
+    return guarded([&] {
+        ZV_NEED(m && x && out, "null argument");
+        ZV_NEED(rows > 0, "rows must be > 0");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        M.select_lane(0);
+        ZV_NEED(!M.graph_mode, "zv_debug_layer runs eagerly: turn graph mode off");
+        const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+        std::vector<float> zsty(E, 0.f);
+        const float *sty = style ? style : zsty.data();
+        M.dbg_layer = Model::DebugLayer();
+        M.dbg_layer.kind = kind;
+        M.dbg_layer.index = index;
+        M.dbg_layer.x = x;
+        M.dbg_layer.out = out;
+        struct Reset { Model &M; ~Reset() { M.dbg_layer = Model::DebugLayer(); } } reset{M};
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        if (kind == ZV_LAYER_VOC_RESBLOCK)
+        {
+            const int stage = index / (int)M.hp.voc_num_resblocks;
+            ZV_NEED(index >= 0 && stage < (int)M.hp.voc_num_upsamples, "residual block index out of range");
+            const uint32_t rate = (uint32_t)M.voc_stage_rate(stage);
+            ZV_NEED(rows % rate == 0, "rows must be a multiple of the stage's samples per frame");
+            const uint32_t T = rows / rate;
+            check_T(M, T);
+            char *io = (char *)M.io_scratch(al((size_t)T * Mm * 4) + (size_t)T * hop * 4);
+            ZV_HIP(hipMemsetAsync(io, 0, (size_t)T * Mm * 4, M.stream));
+            M.vocode_dev(zv::Batch::single(1, T, 1), (const float *)io, (float *)(io + al((size_t)T * Mm * 4)));
+        }
+        else if (kind == ZV_LAYER_ENC_FFT || kind == ZV_LAYER_VAR_PRED)
+        {
+            const uint32_t n = rows, T = 8;
+            char *io = (char *)M.io_scratch(256 + 2 * al((size_t)n * 4) + al(E * 4) + (size_t)T * E * 4);
+            int32_t *d_nf = (int32_t *)io;
+            int32_t *d_ids = (int32_t *)(io + 256), *d_pun = (int32_t *)(io + 256 + al((size_t)n * 4));
+            float *d_sty = (float *)(io + 256 + 2 * al((size_t)n * 4)), *d_hid = (float *)((char *)d_sty + al(E * 4));
+            ZV_HIP(hipMemsetAsync(io, 0, 256 + 2 * al((size_t)n * 4), M.stream));
+            ZV_HIP(hipMemcpyAsync(d_sty, sty, E * 4, hipMemcpyHostToDevice, M.stream));
+            M.encode_dev(zv::Batch::single(n, T, n), d_ids, d_pun, d_sty, d_hid, d_nf);
+        }
+        else if (kind == ZV_LAYER_DEC_BLOCK)
+        {
+            const uint32_t T = rows;
+            check_T(M, T);
+            const size_t b_hid = al((size_t)T * E * 4), b_sty = al(E * 4);
+            char *io = (char *)M.io_scratch(b_hid + b_sty + (size_t)T * Mm * 4);
+            float *d_sty = (float *)io, *d_hid = (float *)(io + b_sty), *d_mel = (float *)(io + b_sty + b_hid);
+            ZV_HIP(hipMemsetAsync(d_hid, 0, b_hid, M.stream));
+            ZV_HIP(hipMemcpyAsync(d_sty, sty, E * 4, hipMemcpyHostToDevice, M.stream));
+            M.decode_dev(zv::Batch::single(1, T, 1), d_hid, d_sty, d_mel);
+        }
+        else
+            zv::fail(ZV_ERR_ARG, "unknown layer kind %d", kind);
+        M.sync();
+        if (!M.dbg_layer.done) zv::fail(ZV_ERR_ARG, "layer (%d, %d) does not exist in this model", kind, index);
+    });
+}
+
 // ---- device-resident entry points ---------------------------------------------------------------
 
 void *zv_device_alloc(zv_model *m, size_t bytes)

@@ -850,9 +850,11 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     // every staging load of the tile is in flight before the first one is consumed (one HBM round trip instead of one
     // per batch of four: measured 6.7 of a workgroup's 20.5 us at 64 channels)
     // (the merged variant holds the running sum of the branches: it keeps the short batches and its occupancy)
-    constexpr int STAGE_U = MERGE ? ZV_STAGE_U : ((CP == 32) ? 10 : (CP == 64 ? 12 : 8));
+    constexpr int STAGE_U = MERGE ? ZV_STAGE_U : ((CP == 32) ? 10 : (CP == 64 ? 12 : ZV_STAGE_U));
+    // (the wide stages keep their registers for occupancy: their first fragments are requested right before the loops)
+    constexpr bool EARLY_B = CP <= 64 && !MERGE;
     half8 bw[4][NT];
-    deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
+    if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
     if (!(P.dbg & 1)) stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
     ZV_STAMP(1)
     __syncthreads();
@@ -869,8 +871,9 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
                 for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
+    if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
     if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw);
-    deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
+    if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
     ZV_STAMP(3)
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
     ZV_STAMP(4)
@@ -917,6 +920,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     ZV_STAMP(5)
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
+    if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);
     if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or

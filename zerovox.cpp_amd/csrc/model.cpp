@@ -693,6 +693,27 @@ ConvJob Model::job(const ConvW &w) const
     return j;
 }
 
+void Model::dbg_inject(void *dev, int ld, int cols, size_t rows)
+{
+    ZV_HIP(hipMemcpy2DAsync(dev, (size_t)ld * 4, dbg_layer.x, (size_t)cols * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, stream));
+}
+
+void Model::dbg_extract(const void *dev, int ld, int cols, size_t rows)
+{
+    ZV_HIP(hipMemcpy2DAsync(dbg_layer.out, (size_t)cols * 4, dev, (size_t)ld * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost, stream));
+    ZV_HIP(hipStreamSynchronize(stream));
+    dbg_layer.done = true;
+}
+
+int Model::voc_stage_rate(int stage) const
+{
+    int r = 1;
+    for (int i = 0; i <= stage && i < voc_.n_up; i++) r *= voc_.scales[i];
+    return r;
+}
+
+int Model::voc_stage_channels(int stage) const { return voc_.in_conv.Cout >> (stage + 1); }
+
 void Model::conv(const ConvJob *jobs, int n, const Segs &segs, int rate, const char *name, double bytes, double flops)
 {
     ZV_LAUNCH(name, bytes, flops, launch_conv(stream, jobs, n, n_cu, segs, rate));
@@ -783,6 +804,8 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
         L = Lo;
         rate *= s;
         C = Cout;
+        const bool dbg_here = dbg_layer.kind == 0 && dbg_layer.index / voc_.n_rb == i;
+        if (dbg_here) dbg_inject(ub, Cp, Cout, L);
         const long Lbatch = (long)bt.t_max * rate * bt.nseg;       // rows the launches of this stage cover
 
         // V2: the 3 MRF branches run side by side (one job each).  Fused path: one launch per dilation
@@ -887,7 +910,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
             }
             // the last pair of the stage: the three branches' outputs are only ever used summed (MRF, :300-315), so the
             // workgroups run all three branches of a tile and store the sum alone
-            const bool merge = fused && !no_merge_ && d == voc_.n_dil - 1;
+            const bool merge = fused && !no_merge_ && !dbg_here && d == voc_.n_dil - 1;
             if (merge)
             {
                 float *ms = (pj[0].out != pj[0].y && pj[0].out != pj[1].y && pj[0].out != pj[2].y) ? pj[0].out : nullptr;
@@ -904,6 +927,11 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
             }
         }
         group_end("voc_resblock_conv");
+        if (dbg_here)
+        {
+            dbg_extract(ycur[dbg_layer.index % voc_.n_rb], Cp, Cout, L);
+            return;
+        }
         for (int jb = 0; jb < 3; jb++) y[jb] = const_cast<float *>(ycur[jb]);
         for (int jb = 0; jb < 3; jb++) prev_y[jb] = y[jb];
         prev_merged = merged_sum;
@@ -1090,8 +1118,18 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     // The partial sums of x's statistics are in part_o (channels [0, Cpart) of x; the others are final in st_in already);
     // the block leaves the partial sums of its output in part_o again when want_stats.  gb_seg: per-segment stride of the
     // affine vectors (0 for the encode blocks' shared InstanceNorm weights, hs for the decode blocks' AdaIN vectors).
+    int blk_no = 0;              // 0,1: encode blocks; 2..6: decode blocks (dbg_layer.index)
     auto block = [&](const DecBlk &b, const float *x, int ldx, int Cpart, float *st_in, const float *g1, const float *b1,
                      const float *g2, const float *b2, int gb_seg, float *out, int ldo, bool want_stats) {
+        const bool dbg_here = dbg_layer.kind == 2 && dbg_layer.index == blk_no && !dbg_layer.done;
+        blk_no++;
+        if (dbg_layer.done) return;
+        if (dbg_here)
+        {   // the layer's input comes from the host; its statistics are recomputed for every channel
+            dbg_inject(const_cast<float *>(x), ldx, b.cin, L);
+            ZV_HIP(launch_stats_partial(stream, x, ldx, b.cin, part_o, nblk, fr, 1));
+            Cpart = b.cin;
+        }
         const float *res = x;
         int ldres = ldx;
         ConvJob jj[2];
@@ -1142,6 +1180,7 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
             }
             conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Cm, b.cout, 3, true), conv_flops(Ld, Cm, b.cout, 3));
         }
+        if (dbg_here) dbg_extract(out, ldo, b.cout, L);
     };
 
     // encode0 / encode1: ResBlk1d with affine InstanceNorm                         (src/stylettsdec.cpp:69-149,373-374)
@@ -1149,6 +1188,7 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     block(dec_.enc[1], x0, B, B, st_y, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, 0, cat, CAT, true);
 
     // asr_res = IN_affine(conv1x1(enc_seq) + b) written straight into the concat buffer      (:382-404)
+    if (dbg_layer.done) return;
     {
         ConvJob j = job(dec_.asr0);
         j.x0 = d_hidden;
@@ -1180,6 +1220,7 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         ldc = ldos[i];
     }
     // to_out: conv1x1 E -> num_mels + b, emitted frame-major                                       (:432-441)
+    if (dbg_layer.done) return;
     {
         ConvJob j = job(dec_.to_out);
         j.x0 = cur;
@@ -1224,8 +1265,12 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
               launch_embed(stream, d_ids, d_puncts, enc_.wemb, hp.emb_dim, enc_.pemb, hp.punct_emb_dim, enc_.posenc, x, Ed, tk));
     const float temperature = (float)pow((double)dk, 0.5);               // src/fs2encoder.cpp:66
     const float inv_t = (float)(1.0 / temperature);                      // :107
+    int layer_no = 0;
     for (const EncLayer &Ly : enc_.layers)
     {
+        const bool dbg_here = dbg_layer.kind == 1 && dbg_layer.index == layer_no;
+        layer_no++;
+        if (dbg_here) dbg_inject(x, Ed, Ed, n);
         ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * nd * Ed), 6.0 * nd * Ed * Ed,
                   launch_linear(stream, x, Ed, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr, tk));
         ZV_LAUNCH("enc_attention", 16.0 * nd * Ed, 4.0 * nd * bt.n_max * Ed,
@@ -1250,11 +1295,21 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
         }
         ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
                   launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk));
+        if (dbg_here)
+        {
+            dbg_extract(x, Ed, Ed, n);
+            return t;
+        }
     }
     // features = encoder output + style_embed                                             (:550-552)
     ZV_LAUNCH("enc_add_style", 8.0 * nd * Ed, 1.0 * nd * Ed, launch_add_rowvec(stream, x, Ed, Ed, d_styles, Ed, tk));
 
+    int pred_no = 0;
     auto predictor = [&](const VarPred &v, float *out) {        // VariancePredictor::graph (:386-440)
+        const bool dbg_here = dbg_layer.kind == 3 && dbg_layer.index == pred_no && !dbg_layer.done;
+        pred_no++;
+        if (dbg_layer.done) return;
+        if (dbg_here) dbg_inject(x, Ed, Ed, n);
         ConvJob a = job(v.c1);
         a.x0 = x;
         a.eact = 1;
@@ -1273,12 +1328,15 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
         ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
                   launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tk));
         ZV_LAUNCH("enc_rowdot", 4.0 * nd * v.V, 2.0 * nd * v.V, launch_rowdot(stream, vb, Vp, v.V, v.lw, v.lb, out, tk));
+        if (dbg_here) dbg_extract(out, 1, 1, n);
     };
     predictor(enc_.dur, t.logdur);
     predictor(enc_.pitch, t.pitch);
+    if (dbg_layer.done) return t;
     ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
               launch_bucket_embed_add(stream, t.pitch, hp.encoder_ve_n_bins, enc_.pitch_emb, Ed, x, Ed, t.pitch_bucket, tk));
     predictor(enc_.energy, t.energy);                           // sees the pitch-augmented features (:569-572)
+    if (dbg_layer.done) return t;
     ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
               launch_bucket_embed_add(stream, t.energy, hp.encoder_ve_n_bins, enc_.energy_emb, Ed, x, Ed, t.energy_bucket, tk));
     ZV_LAUNCH("enc_length_regulator", 4.0 * (nd + (double)bt.t_rows) * Ed, 0.0,

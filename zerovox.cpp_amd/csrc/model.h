@@ -109,8 +109,23 @@ class Model
     EncoderTaps encode_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles,
                            float *d_hidden, int32_t *d_nframes);
 
+    // One layer at a time (the counterpart of the reference's tensor_dbg, src/utils.cpp:19-44; tests only): while
+    // `dbg_layer.kind >= 0` the stage that owns the layer replaces the layer's input with dbg_layer.x (host, time-major,
+    // unpadded) right before it runs, copies the layer's output to dbg_layer.out right after it and returns.
+    // kinds (include/zerovox_amd.h zv_layer_kind): 0 HiFi-GAN residual block n, 1 encoder FFT block l,
+    // 2 decoder residual block b (0,1 encode; 2..6 decode), 3 variance predictor p (0 duration, 1 pitch, 2 energy)
+    struct DebugLayer
+    {
+        int          kind = -1, index = 0;
+        const float *x = nullptr;
+        float       *out = nullptr;
+        bool         done = false;
+    } dbg_layer;
+
     void reserve(uint32_t max_phonemes, uint32_t max_frames);
     void reserve_batch(const Batch &b);
+    int  voc_stage_rate(int stage) const;       // samples per frame after upsample stage `stage`
+    int  voc_stage_channels(int stage) const;
     // largest frame count one segment may have: byte offsets inside a segment are 32-bit in the buffer descriptors
     uint32_t max_frames_per_utterance() const;
     int wemb_rows() const { return enc_.wemb_rows; }
@@ -221,6 +236,8 @@ class Model
 
     // ---- launch helpers ----
     void conv(const ConvJob *jobs, int n, const Segs &segs, int rate, const char *name, double bytes, double flops);
+    void dbg_inject(void *dev, int ld, int cols, size_t rows);
+    void dbg_extract(const void *dev, int ld, int cols, size_t rows);
     ConvJob job(const ConvW &w) const;
     void tick(const char *name, double bytes, double flops, hipEvent_t *e0);
     void tock(hipEvent_t e0, const char *name, double bytes, double flops);
