@@ -161,3 +161,109 @@ def test_converted_checkpoint_loads_and_runs(tmp_path):
     wav, nf = m.synthesize(ids, puncts, style, 32)
     assert wav.shape == (32 * g.hop_size,) and np.isfinite(wav).all() and 0 < nf <= 32
     m.close()
+
+
+def _torch_generator(g, seed):
+    """A HiFi-GAN generator built from torch modules the way the training code builds it (weight-normed Conv1d /
+    ConvTranspose1d, ParallelWaveGAN `hifigan.v1` topology that the reference's graph restates, src/hifigan.cpp:187-356):
+    the un-converted side of the end-to-end check."""
+    import torch
+    from torch import nn
+    from torch.nn.utils import weight_norm
+    torch.manual_seed(seed)
+
+    class ResidualBlock(nn.Module):
+        def __init__(self, k, ch, dils):
+            super().__init__()
+            self.convs1 = nn.ModuleList([nn.Sequential(nn.LeakyReLU(0.1), nn.Conv1d(ch, ch, k, dilation=d, padding=(k - 1) // 2 * d)) for d in dils])
+            self.convs2 = nn.ModuleList([nn.Sequential(nn.LeakyReLU(0.1), nn.Conv1d(ch, ch, k, dilation=1, padding=(k - 1) // 2)) for d in dils])
+
+    class Generator(nn.Module):
+        def __init__(self):
+            super().__init__()
+            C = g.voc_channels
+            self.input_conv = nn.Conv1d(g.num_mels, C, g.voc_kernel_size, padding=(g.voc_kernel_size - 1) // 2)
+            self.upsamples, self.blocks = nn.ModuleList(), nn.ModuleList()
+            for i, (s, k) in enumerate(zip(g.upsample_scales, g.upsample_kernels)):
+                self.upsamples.append(nn.Sequential(nn.LeakyReLU(0.1), nn.ConvTranspose1d(C >> i, C >> (i + 1), k, s, padding=s // 2 + s % 2, output_padding=s % 2)))
+                for rk in g.resblock_kernels:
+                    self.blocks.append(ResidualBlock(rk, C >> (i + 1), g.resblock_dilations))
+            self.output_conv = nn.Sequential(nn.LeakyReLU(0.01), nn.Conv1d(C >> len(g.upsample_scales), 1, g.voc_kernel_size, padding=(g.voc_kernel_size - 1) // 2), nn.Tanh())
+            for m in self.modules():
+                if isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
+                    weight_norm(m)
+            with torch.no_grad():               # speech-like output level: the 1e-4 RMS gate is absolute
+                for b in self.blocks:
+                    for c in b.convs2:
+                        c[1].weight_g.mul_(0.3)
+
+    return Generator().double()
+
+
+def _generator_forward_ggml_semantics(gen, g, mel, mean, scale):
+    """the torch modules' forward, un-converted weights, with operands rounded where the reference's ggml graph rounds them:
+    every conv rounds its input activations (im2col) and its weight to f16, products accumulate in f32 or better
+    (here float64); (mel - mean) / scale in front (src/hifigan.cpp:242-243)"""
+    import torch
+    import torch.nn.functional as F
+
+    def h(t):                      # round to f16, keep computing in f64
+        return t.float().half().double()
+
+    def w_of(conv):                # the folded weight: g * v / ||v||, rounded to f16 like the stored tensor
+        v, gm = conv.weight_v, conv.weight_g
+        w = v * (gm / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        return h(w.float())
+
+    def conv(c, x):
+        return F.conv1d(h(x.float()), w_of(c), c.bias, dilation=c.dilation, padding=c.padding)
+
+    def deconv(c, x):
+        return F.conv_transpose1d(h(x.float()), w_of(c), c.bias, stride=c.stride, padding=c.padding, output_padding=c.output_padding)
+
+    lrelu = lambda t, s: F.leaky_relu(t.float(), s).double()          # noqa: E731  (activations are f32 tensors in the reference)
+    with torch.no_grad():
+        x = ((torch.from_numpy(mel).float() - torch.from_numpy(mean).float()) / torch.from_numpy(scale).float()).T[None].double()
+        x = conv(gen.input_conv, x).float().double()
+        nb = len(g.resblock_kernels)
+        for i in range(len(g.upsample_scales)):
+            x = deconv(gen.upsamples[i][1], lrelu(x, 0.1)).float().double()
+            cs = None
+            for j in range(nb):
+                blk, y = gen.blocks[i * nb + j], x
+                for c1, c2 in zip(blk.convs1, blk.convs2):
+                    xt = conv(c1[1], lrelu(y, 0.1)).float().double()
+                    xt = conv(c2[1], lrelu(xt, 0.1)).float().double()
+                    y = (xt.float() + y.float()).double()
+                cs = y if cs is None else (cs.float() + y.float()).double()
+            x = (cs.float() * torch.tensor(1.0 / nb).float()).double()
+        x = torch.tanh(conv(gen.output_conv[1], lrelu(x, 0.01)).float())
+    return x[0, 0].numpy().astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", ["tiny", "small"])
+def test_torch_generator_forward_equals_gpu_on_converted_checkpoint(tmp_path, geom):
+    """f-1 end to end: torch forward of the UN-converted modules (weight_norm parametrisation, ConvTranspose1d) == the GPU
+    vocoder on the file convert.py writes from their state dict (weight-norm fold, deconv flip + permute, name
+    shortening, F16 casts; reference utils/zv2gguf.py:96-107,164-180, src/hifigan.cpp:22-71)"""
+    from zerovox_cpp_amd import capi, convert, synth
+    g = synth.GEOMETRIES[geom]
+    sd, _, stats, _ = _training_checkpoint(g, 78)
+    gen = _torch_generator(g, 5)
+    gen_sd = {k: v.detach().float() for k, v in gen.state_dict().items()}
+    assert any(k.endswith("weight_v") for k in gen_sd) and "upsamples.0.1.weight_g" in gen_sd
+    out = str(tmp_path / "conv.gguf")
+    convert.convert(sd, _cfg(g), stats, out, meldec_generator=gen_sd)
+    m = capi.Model(out, 0)
+    T = 40
+    mean, scale = stats["mean"].astype(np.float32), stats["scale"].astype(np.float32)
+    mel = (mean[None, :] + scale[None, :] * np.random.default_rng(3).standard_normal((T, g.num_mels))).astype(np.float32)
+    wav = m.vocode(mel)
+    m.close()
+    ref = _generator_forward_ggml_semantics(gen, g, mel, mean, scale)
+    assert ref.shape == wav.shape == (T * g.hop_size,)
+    err = float(np.sqrt(np.mean((wav.astype(np.float64) - ref) ** 2)))
+    sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    print(f"{geom}: torch generator vs GPU on the converted file: wav rms err {err:.3e} (signal rms {sig:.3f})")
+    assert 0.02 < sig < 0.6 and err <= 1e-4
