@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch of the HiFi-GAN ResBlock kernel family from the PMC passes (FETCH_SIZE doubled as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads, + WRITE_SIZE), weighted over the
+family's launches, with the launch durations of the kernel trace of the same build.
+usage: traffic.py <pmc.txt> <kernel_trace_summary.txt> <tag>"""
+import json, re, sys
+pmc, trace, tag = sys.argv[1:4]
+fam = ("resblock_pair_kernel", "resblock_triple_kernel")
+fetch, write, n = {}, {}, {}
+sect = None
+for ln in open(pmc):
+    if ln.startswith("#"):
+        sect = ln
+        continue
+    if not ln.startswith(fam):
+        continue
+    key = ln.split(" grid ")[0] + " grid " + ln.split(" grid ")[1].split()[0]
+    m = re.search(r"FETCH_SIZE=([0-9.e+]+)", ln)
+    if m:
+        fetch[key] = float(m.group(1)) * 1024 * 2          # KB -> bytes, x2: gfx950 tallies 128-B requests at 64 B
+        n[key] = int(re.search(r"n=(\d+)", ln).group(1))
+    m = re.search(r"WRITE_SIZE=([0-9.e+]+)", ln)
+    if m:
+        write[key] = float(m.group(1)) * 1024
+dur = {}
+for ln in open(trace):
+    if not ln.startswith(fam):
+        continue
+    name = ln.split("grid=")[0].strip()
+    g = re.search(r"grid=\((\d+),(\d+),(\d+)\)", ln)
+    key = "%s grid %d" % (name, int(g.group(1)) * int(g.group(2)) * int(g.group(3)))
+    dur[key] = (int(re.search(r"calls=(\d+)", ln).group(1)), float(re.search(r"avg_us=([0-9.]+)", ln).group(1)))
+tot_b = tot_n = tot_us = 0.0
+per = {}
+for k in fetch:
+    if k not in write:
+        continue
+    calls, us = dur.get(k, (n[k], 0.0))
+    b = fetch[k] + write[k]
+    per[k] = {"hbm_bytes_per_launch": b, "avg_launch_us": us, "GBps": round(b / (us * 1e-6) / 1e9, 1) if us else None}
+    tot_b += b * n[k]
+    tot_n += n[k]
+    tot_us += us * n[k]
+out = {"kernel_rev": tag, "workload": "bench.py batch: 32 utterances x 1024 frames per launch",
+       "hbm_bytes_per_launch": tot_b / tot_n if tot_n else None, "avg_launch_us": tot_us / tot_n if tot_n else None,
+       "method": "per kernel configuration: 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, separate --pmc passes; "
+                 "averaged over the family's dispatches; durations from the kernel trace of the same build",
+       "per_kernel": per}
+print(json.dumps(out, indent=1))
