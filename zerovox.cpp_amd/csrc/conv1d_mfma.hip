@@ -371,7 +371,7 @@ __device__ __forceinline__ void deep_preload_b(half8 (&b0)[4][NT], const half8 *
 
 template <int CP, int MT, int NT, bool SWAP, int DEPTH = 2>
 __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K,
-                                               half8 (&b0)[4][NT])
+                                               half8 (&b0)[4][NT], int wstep = 8 * 64)
 {
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     constexpr int TPB = (NKC >= 8) ? 1 : 8 / NKC;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         ZV_STEP2(4, b1) ZV_STEP2(5, b1) ZV_STEP2(6, b1) ZV_STEP2(7, b1)                                          \
         ap = apn;                                                                                                \
-        wq += 8 * 64;                                                                                            \
+        wq += wstep;                                                                                             \
     }
     {
         const char *tb[4], *tbn[4];
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
     if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw, (P.dbg & 32) ? 0 : 8 * 64);
     if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
     ZV_STAMP(3)
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
     if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw);
+    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw, (P.dbg & 32) ? 0 : 8 * 64);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
     // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a

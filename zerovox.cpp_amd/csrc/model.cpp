@@ -146,6 +146,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     no_triple_ = getenv("ZV_NO_TRIPLE") && atoi(getenv("ZV_NO_TRIPLE")) != 0;
     force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
     no_merge_ = getenv("ZV_NO_MERGE") && atoi(getenv("ZV_NO_MERGE")) != 0;
+    voc_group_ = getenv("ZV_VOC_GROUP") ? atoi(getenv("ZV_VOC_GROUP")) : 0;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
     lanes_[0].stream = stream;
@@ -734,11 +735,30 @@ static double conv_flops(double L, int Cin, int Cout, int K) { return 2.0 * L * 
 void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
 {
     if (bt.t_rows == 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "T must be > 0");
+    // ZV_VOC_GROUP=G (experiment): the vocoder runs G utterances at a time, so that the tensors one launch hands to the
+    // next stay in the 256 MiB Infinity Cache instead of crossing HBM twice; same buffers, same row ranges, same bits
+    if (voc_group_ > 0 && bt.d_frm && bt.nseg > voc_group_ && dbg_layer.kind < 0)
+    {
+        for (int g0 = 0; g0 < bt.nseg; g0 += voc_group_)
+        {
+            Batch sub = bt;
+            sub.d_frm = bt.d_frm + g0;
+            sub.nseg = std::min(voc_group_, bt.nseg - g0);
+            vocode_group(sub, d_mel, d_wav);
+        }
+        return;
+    }
+    vocode_group(bt, d_mel, d_wav);
+}
+
+void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav)
+{
     arena_require(arena_bytes_for(1, bt.t_rows, bt.nseg));
     arena_.used = 0;
     const Segs fr = bt.frames();
     const int M = hp.audio_num_mels;
-    size_t L = bt.t_rows;                       // capacity rows at the current stage
+    size_t L = bt.t_rows;                       // capacity rows at the current stage (buffer sizes)
+    double La = std::min((double)bt.t_rows, (double)bt.t_max * bt.nseg);      // rows this call covers (accounting)
     int rate = 1;
     int C = voc_.in_conv.Cout;
     float *c0 = arena_.take_n<float>(L * voc_.in_conv.Cout_p);
@@ -752,7 +772,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
         j.pa = voc_.mean;
         j.pb = voc_.scale;
         j.out = c0;
-        conv(&j, 1, fr, rate, "voc_input_conv", conv_bytes((double)L, M, C, j.K, false), conv_flops((double)L, M, C, j.K));
+        conv(&j, 1, fr, rate, "voc_input_conv", conv_bytes(La, M, C, j.K, false), conv_flops(La, M, C, j.K));
     }
 
     char *pool_base[2];
@@ -798,10 +818,11 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
             else { j.x0 = prev_y[0]; j.x1 = prev_y[1]; j.x2 = prev_y[2]; j.pro = PRO_SUM3_ACT; j.pscale = third; }
             j.out = ub;
             // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
-            conv(&j, 1, fr, rate, "voc_upsample", 4.0 * L * C * (i == 0 ? 1 : 3) + 4.0 * Lo * Cout + 2.0 * C * Cout * 2 * s,
-                 2.0 * L * C * Cout * 2 * s);
+            conv(&j, 1, fr, rate, "voc_upsample", 4.0 * La * C * (i == 0 ? 1 : 3) + 4.0 * La * s * Cout + 2.0 * C * Cout * 2 * s,
+                 2.0 * La * C * Cout * 2 * s);
         }
         L = Lo;
+        La *= s;
         rate *= s;
         C = Cout;
         const bool dbg_here = dbg_layer.kind == 0 && dbg_layer.index / voc_.n_rb == i;
@@ -852,8 +873,8 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
                     t.b1[d] = rp.c1.bias;
                     t.b2[d] = rp.c2.bias;
                     t.dil[d] = voc_.dil[d];
-                    bb += conv_bytes((double)L, C, C, rp.c1.K, false) + conv_bytes((double)L, C, C, rp.c2.K, true);
-                    ff += conv_flops((double)L, C, C, rp.c1.K) + conv_flops((double)L, C, C, rp.c2.K);
+                    bb += conv_bytes(La, C, C, rp.c1.K, false) + conv_bytes(La, C, C, rp.c2.K, true);
+                    ff += conv_flops(La, C, C, rp.c1.K) + conv_flops(La, C, C, rp.c2.K);
                 }
                 ycur[jb] = y[jb];
             }
@@ -903,10 +924,10 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
                 p.dil = voc_.dil[d];
                 p.slope = 0.1f;
                 ycur[jb] = fused ? yout : y[jb];
-                b1 += conv_bytes((double)L, C, C, rp.c1.K, false);
-                f1 += conv_flops((double)L, C, C, rp.c1.K);
-                b2 += conv_bytes((double)L, C, C, rp.c2.K, true);
-                f2 += conv_flops((double)L, C, C, rp.c2.K);
+                b1 += conv_bytes(La, C, C, rp.c1.K, false);
+                f1 += conv_flops(La, C, C, rp.c1.K);
+                b2 += conv_bytes(La, C, C, rp.c2.K, true);
+                f2 += conv_flops(La, C, C, rp.c2.K);
             }
             // the last pair of the stage: the three branches' outputs are only ever used summed (MRF, :300-315), so the
             // workgroups run all three branches of a tile and store the sum alone
@@ -954,7 +975,7 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
         a.out = d_wav;
         a.segs = fr;
         a.rate = rate;
-        ZV_LAUNCH("voc_output_conv", 12.0 * L * C + 4.0 * L, 2.0 * L * C * a.K, launch_out_conv(stream, a));
+        ZV_LAUNCH("voc_output_conv", 12.0 * La * C + 4.0 * La, 2.0 * La * C * a.K, launch_out_conv(stream, a));
     }
 }
 

@@ -98,6 +98,7 @@ class Model
     // every tensor is the row concatenation over the batch: mel [t_rows][M], wav [t_rows * hop], hidden [t_rows][E],
     // ids / puncts [n_rows], styles [nseg][E]
     void vocode_dev(const Batch &b, const float *d_mel, float *d_wav);
+    void vocode_group(const Batch &b, const float *d_mel, float *d_wav);
     void decode_dev(const Batch &b, const float *d_hidden, const float *d_styles, float *d_mel);
     // taps are device pointers inside the arena (token rows as in ids), valid until the next call;
     // n_frames [nseg] is written to d_nframes (outside the arena)
@@ -263,6 +264,7 @@ class Model
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
+    int  voc_group_ = 0;          // ZV_VOC_GROUP=G: utterances per vocoder pass of a batch (0 = all at once)
     bool no_merge_ = false;       // ZV_NO_MERGE=1: the last dilation pair of a stage stores its three branch outputs instead of their sum (A/B, tests)
     bool force_fuse256_ = false;  // ZV_FUSE256=1: fused kernel for the 256-channel stage at any length (tests: the path
                                   // long / batched utterances take, exercised at sizes the CPU oracle can check)
