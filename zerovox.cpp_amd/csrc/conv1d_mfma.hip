@@ -1050,13 +1050,13 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // bound by the weight stream from L2 (1 KiB of B fragment per 2 MFMAs per wave at MT = 2) and BM = 128 is 14 % faster;
     // the 64-channel stage does not care (-1 %).  The tile height never changes an output bit.
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
-    if ((mt_env == 2 || mt_env == 4) && Cp != 256) MT = mt_env;
+    if (mt_env == 2 || mt_env == 4) MT = mt_env;
     js.kmax = Kmax;
 #define ZV_PCASE(cp, mt)                                                                                 \
     if (Cp == cp && MT == mt)                                                                            \
         return merge_out ? launch_pair_cfg<cp, mt, true>(s, js, njobs, Lmax, Kmax, dmax)                 \
                          : launch_pair_cfg<cp, mt, false>(s, js, njobs, Lmax, Kmax, dmax);
-    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2)
+    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2) ZV_PCASE(256, 4)
 #undef ZV_PCASE
     return hipErrorInvalidValue;
 }
