@@ -194,7 +194,9 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
     mel = synth.vocoder_mel(g, tensors, 51, 384)
     outs = {}
     for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"}),
-                      ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"})):
+                      ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"}),
+                      ("block_v1", {"ZV_TRIPLE_V2": "0"}), ("block_v2", {"ZV_TRIPLE_V2": "2"}),
+                      ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"})):
         os.environ.update(env)
         try:
             m = capi.Model(path, 0)

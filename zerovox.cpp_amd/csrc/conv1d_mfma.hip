@@ -741,6 +741,14 @@ __device__ __forceinline__ float lrelu_max(float x, float s)
     return r;
 }
 
+// max(x, xs) with xs = x * slope already formed (packed multiplies)
+__device__ __forceinline__ float lrelu_max_pre(float x, float xs)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(xs));
+    return r;
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
@@ -1234,6 +1242,239 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The whole-block kernel, second form (batches): the conv weights go through LDS.
+// In the kernel above every wave streams its own copy of every B fragment from L1/L2 (1 KiB per two MFMAs per wave: the
+// CU's vector-memory path is the busiest unit of the launch) through a 32-register ring, which puts the kernel at 150
+// registers: ONE 8-wave workgroup per CU, whose waves sit in the same phase between the same barriers, so the matrix
+// pipe idles during every pack / epilogue phase and the vector ALUs during every MFMA loop.  Here the 8 ... 24 KiB of a
+// conv's fragments are copied global -> LDS once per workgroup (LDS-DMA, one 1-KiB fragment per wave-instruction, no
+// registers) while the waves write the operand tile, both MFMA operands are ds_read_b128s two steps ahead, and the
+// kernel fits 128 registers: two workgroups per CU, one in its MFMA loop while the other packs.  Same operations in the
+// same order per output element as resblock_triple_kernel / resblock_pair_kernel, hence the same bits.
+__device__ __forceinline__ void dma_weights32(const void *wsrc, char *wlds, int nblk, int wave, int lane, int nwv)
+{
+    for (int blk = wave; blk < nblk; blk += nwv)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)wsrc + blk * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(wlds + blk * 1024), 16, 0, 0);
+}
+
+// one conv of the 32-channel block: nb bodies of 8 steps (4 taps x 2 channel halves), A rows and B fragments from LDS,
+// both two steps ahead of the MFMAs that consume them (four register sets in rotation, a scheduling fence per step)
+template <int MT, bool SWAP>
+__device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *ap, int dilRS, const char *wl, int nb)
+{
+    constexpr int RS = 32 * 2 + 16;
+    half8 a[4][MT], b[4][1];
+#define ZV_LD(slot, aptr, woff)                                                                                       \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
+        b[slot][0] = *(const half8 *)(wl + (woff));                                                                   \
+    }
+#define ZV_ST(slot, Z)                                   \
+    mfma_step<MT, 1, SWAP, Z>(acc, a[slot], b[slot]);    \
+    __builtin_amdgcn_sched_barrier(0);
+#define ZV_BODY32(Z0)                                                                         \
+    {                                                                                         \
+        const char *t1 = ap + dilRS, *t2 = t1 + dilRS, *t3 = t2 + dilRS, *apn = t3 + dilRS;   \
+        ZV_LD(2, t1, 2 * 1024) ZV_ST(0, Z0)                                                   \
+        ZV_LD(3, t1 + 32, 3 * 1024) ZV_ST(1, false)                                           \
+        ZV_LD(0, t2, 4 * 1024) ZV_ST(2, false)                                                \
+        ZV_LD(1, t2 + 32, 5 * 1024) ZV_ST(3, false)                                           \
+        ZV_LD(2, t3, 6 * 1024) ZV_ST(0, false)                                                \
+        ZV_LD(3, t3 + 32, 7 * 1024) ZV_ST(1, false)                                           \
+        ZV_LD(0, apn, 8 * 1024) ZV_ST(2, false)                                               \
+        ZV_LD(1, apn + 32, 9 * 1024) ZV_ST(3, false)                                          \
+        ap = apn;                                                                             \
+        wl += 8 * 1024;                                                                       \
+    }
+    ZV_LD(0, ap, 0)
+    ZV_LD(1, ap + 32, 1024)
+    ZV_BODY32(true)
+    for (int ib = 1; ib < nb; ib++) ZV_BODY32(false)
+#undef ZV_BODY32
+#undef ZV_ST
+#undef ZV_LD
+}
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// f16(lrelu(x + b)) of four values: packed add / multiply / convert (v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32: the
+// same IEEE results as the scalar forms), max(x, x*slope) as in lrelu_max
+__device__ __forceinline__ uint2 lrelu4_f16(float x0, float x1, float x2, float x3, float sl)
+{
+    const float2v a = {x0, x1}, c = {x2, x3};
+    const float2v as = a * sl, cs = c * sl;
+    const float2v ra = {lrelu_max_pre(a[0], as[0]), lrelu_max_pre(a[1], as[1])};
+    const float2v rc = {lrelu_max_pre(c[0], cs[0]), lrelu_max_pre(c[1], cs[1])};
+    const half2v ha = __builtin_convertvector(ra, half2v), hc = __builtin_convertvector(rc, half2v);
+    uint2 pk;
+    pk.x = *(const unsigned int *)&ha;
+    pk.y = *(const unsigned int *)&hc;
+    return pk;
+}
+
+// (A variant with Y in the transposed accumulator layout — both convs with the weights as the A operand, 8-byte operand
+// writes, 16-byte tile loads / stores: half the vector instructions — measured 7 % SLOWER: a 16-byte access per lane in
+// that layout touches 32 rows x 32 bytes per instruction, against 2 rows x 128 bytes for the 4-byte column accesses.)
+template <int MT, int R>
+__global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel(const TripleJobs jobs)
+{
+    constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    const TripleJob &P = jobs.j[blockIdx.z];
+    const int K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int sumd = 0, dmax = 1;
+    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+    const int H = h2 * (sumd + nd);
+    const int TM = R - 2 * H;
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
+    const int XM = h2 * dmax;
+    const bool edge = t0 - H < 0 || t0 - H + R > L;
+    const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
+    const int nb = ((K * NKC + 3) >> 2) >> 1;         // 8-step bodies per conv
+    const int nblk = 8 * nb;                          // weight fragments per conv (real ones first, zero blocks behind)
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char *wlds = smem + round_up(xrows * RS, 1024);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31;
+    const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
+
+    dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
+    // the margins of the operand region stay zero for the whole kernel: rows [0, XM) and [XM + R, xrows)
+    {
+        const int lo = XM * RS / 16, hi0 = (XM + R) * RS / 16, hi = xrows * RS / 16;
+        for (int i = tid; i < lo; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = hi0 + tid; i < hi; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+    }
+    // tile row i <-> time t0 - H + i; rows outside [0, L) are out of the descriptor's range and read as 0
+    float yreg[MT][16];
+    {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        const int voff = ((t0 - H + irow0) * CP + col) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                yreg[mt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, voff + (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
+    }
+
+    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
+    const char *wl = wlds + lane * 16;
+    const float sl = P.slope;
+    for (int d = 0; d < nd; d++)
+    {
+        const int dil = P.dil[d], h1 = h2 * dil;
+        if (d)
+        {
+            __syncthreads();                   // the previous conv2 is done reading XT and its weights
+            dma_weights32(P.w1[d], wlds, nblk, wave, lane, NWV);
+        }
+        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
+        {
+            char *xp = smem + (XM + irow0) * RS + col * 2;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    *(_Float16 *)(xp + (mt * 32 + (r & 3) + 8 * (r >> 2)) * RS) = (_Float16)lrelu_max(yreg[mt][r], sl);
+        }
+        __syncthreads();                       // X complete, conv1's weights landed (the barrier drains the DMA)
+
+        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
+        floatx16 acc[MT][1];
+        if (P.dbg & 2)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
+        if (!(P.dbg & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, nb);
+        __syncthreads();                       // every wave is done reading X and conv1's weights
+        dma_weights32(P.w2[d], wlds, nblk, wave, lane, NWV);
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L)
+        {
+            const int hh = lane >> 5;
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1[d] + 8 * q + 4 * hh);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+            {
+                const int i = wave * 32 * MT + mt * 32 + (lane & 31);
+                const int t = t0 - H + i;
+                const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    uint2 pk = lrelu4_f16(acc[mt][0][4 * q + 0] + bq[q].x, acc[mt][0][4 * q + 1] + bq[q].y,
+                                          acc[mt][0][4 * q + 2] + bq[q].z, acc[mt][0][4 * q + 3] + bq[q].w, sl);
+                    if (edge)
+                    {
+                        pk.x = in ? pk.x : 0u;
+                        pk.y = in ? pk.y : 0u;
+                    }
+                    *(uint2 *)(smem + (XM + i) * RS + (8 * q + 4 * hh) * 2) = pk;
+                }
+            }
+        }
+        __syncthreads();                       // XT complete, conv2's weights landed
+
+        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
+        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl, nb);
+        {
+            const float bias = P.b2[d][col];
+            if (edge)
+            {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const int t = t0 - H + irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                        const float v = (acc[mt][0][r] + bias) + yreg[mt][r];
+                        yreg[mt][r] = (t >= 0 && t < L) ? v : 0.f;
+                    }
+            }
+            else
+            {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) yreg[mt][r] = (acc[mt][0][r] + bias) + yreg[mt][r];
+            }
+        }
+    }
+
+    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
+    if (P.dbg & 4) return;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int i = irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int t = t0 - H + i;
+            const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, 0);
+        }
+}
+
 bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 {
     if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || !pair_supported(Cp, K)) return false;
@@ -1273,6 +1514,31 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(round_up(gx, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
+    // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always (A/B, tests)
+    static const int v2_env = getenv("ZV_TRIPLE_V2") ? atoi(getenv("ZV_TRIPLE_V2")) : 1;
+    if (MT == 2 && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
+    {
+        size_t lds2 = 0;
+        for (int i = 0; i < njobs; i++)
+        {
+            const TripleJob &P = jobs[i];
+            int dmax = 1;
+            for (int d = 0; d < P.n_dil; d++) dmax = P.dil[d] > dmax ? P.dil[d] : dmax;
+            const size_t rows = R + 2 * ((P.K - 1) / 2) * dmax + 5 * dmax;
+            const int nb = ((P.K * 2 + 3) >> 2) >> 1;
+            lds2 = std::max(lds2, (size_t)round_up((int)(rows * 80), 1024) + (size_t)(8 * nb + 2) * 1024);   // + 2 fragments: the last B prefetch
+        }
+        if (lds2 <= 80 * 1024)
+        {
+            auto launch = [&](auto kern, int nth) {
+                hipError_t e = lds2 > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) : hipSuccess;
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, grid, dim3(nth), lds2, s, js);
+                return hipGetLastError();
+            };
+            return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
+        }
+    }
 #define ZV_TCASE(mt, r) \
     if (MT == mt && R == r) { hipLaunchKernelGGL((resblock_triple_kernel<32, mt, r>), grid, dim3(64 * (r / 32 / mt)), lds, s, js); return hipGetLastError(); }
     ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
