@@ -196,15 +196,17 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
     for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"}),
                       ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"}),
                       ("block_v1", {"ZV_TRIPLE_V2": "0"}), ("block_v2", {"ZV_TRIPLE_V2": "2"}),
-                      ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"})):
-        os.environ.update(env)
+                      ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"}),
+                      ("pair64_ring", {"ZV_PAIR64_RING": "2"}), ("pair64_ring_no_merge", {"ZV_PAIR64_RING": "2", "ZV_NO_MERGE": "1"}),
+                      ("pair64_no_ring", {"ZV_PAIR64_RING": "0"})):
+        os.environ.update(env)          # some switches are read when the model is built, some at every launch
         try:
             m = capi.Model(path, 0)
+            outs[name] = m.vocode(mel)
+            m.close()
         finally:
             for k in env:
                 del os.environ[k]
-        outs[name] = m.vocode(mel)
-        m.close()
     for name, w in outs.items():
         assert np.array_equal(w, outs["default"]), name
 

@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -657,9 +658,25 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
     int MT = 4;
     while (MT > 1 && wgs(MT, 1) < 2L * n_cu) MT >>= 1;
     while (MT > 1 && (size_t)(32 * MT * (4 / WN) + halo + dmax) * (ck * 2 + 16) > 80 * 1024) MT >>= 1;   // keep >= 2 workgroups per CU in LDS
+    {
+        // memory-bound convs (the polyphase transposed convs of the narrow HiFi-GAN stages: a few hundred MACs per output
+        // element against 8 bytes moved) want workgroups in flight, not weight reuse: measured on the batch, the last
+        // three upsample convs take 897 / 595 / 452 us with the tall tiles and 636 / 569 / 416 us with these
+        const double ai = 2.0 * jobs[0].K * jobs[0].Cin_p * Cout_p / (4.0 * (jobs[0].Cin_p + Cout_p));
+        if (ai < 200.0 && wgs(1, 1) >= 16L * n_cu) MT = std::min(MT, Cout_p <= 128 ? 2 : 1);
+    }
     {   // measurement hook (environment table): ZV_CONV_MT=<minimum MT>
         static const char *e_mt = getenv("ZV_CONV_MT");
         if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
+        // ZV_CONV_MTMAX=<mt>[,<max K*Cin_p>]: cap the tile height (for convs whose contraction is at most that long)
+        static const char *e_mx = getenv("ZV_CONV_MTMAX");
+        if (e_mx)
+        {
+            const int cap = atoi(e_mx);
+            const char *c = strchr(e_mx, ',');
+            const int kmax = c ? atoi(c + 1) : (1 << 30);
+            if (jobs[0].K * jobs[0].Cin_p <= kmax && MT > cap) MT = cap;
+        }
     }
     // two output tiles per wave once a conv is wide and the launch still has rounds of workgroups to spare
     static const int nt_env = getenv("ZV_CONV_NT") ? atoi(getenv("ZV_CONV_NT")) : 0;
@@ -750,6 +767,25 @@ __device__ __forceinline__ float lrelu_max_pre(float x, float xs)
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// f16(lrelu(x + b)) of four values: packed add / multiply / convert (v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32: the
+// same IEEE results as the scalar forms), max(x, x*slope) as in lrelu_max
+__device__ __forceinline__ uint2 lrelu4_f16(float x0, float x1, float x2, float x3, float sl)
+{
+    const float2v a = {x0, x1}, c = {x2, x3};
+    const float2v as = a * sl, cs = c * sl;
+    const float2v ra = {lrelu_max_pre(a[0], as[0]), lrelu_max_pre(a[1], as[1])};
+    const float2v rc = {lrelu_max_pre(c[0], cs[0]), lrelu_max_pre(c[1], cs[1])};
+    const half2v ha = __builtin_convertvector(ra, half2v), hc = __builtin_convertvector(rc, half2v);
+    uint2 pk;
+    pk.x = *(const unsigned int *)&ha;
+    pk.y = *(const unsigned int *)&hc;
+    return pk;
+}
+
 
 // ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
 // stamps the clock at its phase boundaries into a buffer of its own (cdna_hip_programming.md §7, in-kernel stamps)
@@ -990,6 +1026,295 @@ extern "C" int zv_debug_read_stamps(unsigned long long *out, size_t n)
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------
+// The fused dilation pair of the 64-channel stage for batches: weights through an LDS ring.
+// In resblock_pair_kernel<64> every wave streams its own copy of every B fragment from L1 (1 KiB per two MFMAs per wave,
+// the two row halves of a workgroup fetching the same fragments twice): at the matrix pipe's full rate that alone is the
+// whole 64 B/clk of the CU's vector-memory path, which the staging loads, the residual loads and the stores share — the
+// MFMA loops run at 40 % of the pipe's rate (measured: 0.87 ms per launch against 0.36 ms of MFMA time).  Here
+//   * a workgroup is 4 waves x (64 rows x all 64 channels) = 256 rows (halo recompute 1.04 instead of 1.08 at 11 taps),
+//   * the weights of both convs travel global -> LDS once per workgroup as one stream of 2K chunks (one tap = 8 fragments
+//     = 8 KiB each) through a ring of four slots, by LDS-DMA, two chunks ahead of the MFMAs (one workgroup barrier per
+//     tap; the stream keeps running under the xt pack),
+//   * both MFMA operands are ds_read_b128s two steps ahead; one A fragment feeds two MFMAs and so does one B fragment.
+// Vector-memory bytes per output row fall 5x.  Same operations in the same order per output element as
+// resblock_pair_kernel (tap-major, 16 channels per step), hence the same bits.
+// Weight layout (pack_pair_weight_ring): [tap][kc][ntile][lane][8 halfs].
+size_t pair_ring_weight_halfs(int Cp, int K) { return (size_t)K * (Cp / 16) * (Cp / 32) * 512; }
+
+void pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
+{
+    const int nkc = Cp / 16, nnt = Cp / 32;
+    for (int tap = 0; tap < K; tap++)
+        for (int kc = 0; kc < nkc; kc++)
+            for (int nt = 0; nt < nnt; nt++)
+            {
+                uint16_t *d = dst + ((size_t)(tap * nkc + kc) * nnt + nt) * 512;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                    {
+                        const int oc = nt * 32 + (lane & 31), ic = kc * 16 + 8 * (lane >> 5) + j;
+                        d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                    }
+            }
+}
+
+template <bool MERGE>
+__global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs jobs)
+{
+    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
+    constexpr int CHUNK = 8 * 1024;                  // one tap: 4 channel steps x 2 output tiles
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[blockIdx.z].K - 1);
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char *ring = smem + jobs.ring_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
+    const char *bl = ring + lane * 16;
+
+    floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
+    for (int jb = MERGE ? 0 : (int)blockIdx.z; jb < (MERGE ? jobs.njobs : (int)blockIdx.z + 1); jb++)
+    {
+        const PairJob &P = jobs.j[jb];
+        const int K = P.K, dil = P.dil;
+        const int h2 = (K - 1) / 2, h1 = h2 * dil;
+        const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+        float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
+        const int nchunk = 2 * K;
+        // chunk g of the pair's weight stream (conv1's taps, then conv2's) -> ring slot g & 3; a wave moves 2 of its 8 fragments
+        // (the stream's base pointers pinned in scalar registers: re-reading them from the kernel arguments at every request
+        // would put an lgkmcnt(0) wait — which also waits for the LDS reads in flight — into every tap)
+        const uint64_t w1a = (uint64_t)P.w1r + wave * 2048, w2a = (uint64_t)P.w2r + wave * 2048 - (uint64_t)K * CHUNK;
+        const uint32_t w1lo = __builtin_amdgcn_readfirstlane((uint32_t)w1a), w1hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1a >> 32));
+        const uint32_t w2lo = __builtin_amdgcn_readfirstlane((uint32_t)w2a), w2hi = __builtin_amdgcn_readfirstlane((uint32_t)(w2a >> 32));
+        auto issue = [&](int g) {
+            const uint64_t base = g < K ? ((uint64_t)w1hi << 32 | w1lo) : ((uint64_t)w2hi << 32 | w2lo);
+            const char *src = (const char *)base + (size_t)g * CHUNK + lane * 16;
+            char *dst = ring + (g & 3) * CHUNK + wave * 2048;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+        };
+        if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the tile and the ring
+        issue(0);
+        issue(1);
+        issue(2);
+
+        // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        // (two workgroups per CU whatever the register count — LDS decides — so every staging load of the tile is in flight at once)
+        if (!(P.dbg & 1)) stage_act_buf<20, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+        // the residual operand (the tile's centre rows again, in the accumulator layout) is requested right behind the
+        // staging loads, while their lines are still in L2, and waits in registers until the epilogue
+        const int nrows = (L - t0 < TM) ? (L - t0) : TM;
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+        const int voff0 = ((wave * 32 * MT + 4 * (lane >> 5)) * CP + (lane & 31)) * 4;
+        float resv[MT][NT][16];
+        auto load_res = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        resv[mt][nt][r] = (P.dbg & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff0 + nt * 128, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+        };
+        if constexpr (!MERGE) load_res();      // (the merged form holds the branches' running sum: it loads in the epilogue)
+        __syncthreads();                                // X complete; the barrier drains the first three chunks too
+
+        floatx16 acc[MT][NT];
+        half8 a[4][MT], b[4][NT];
+        int g = 0;                                      // chunk = tap of the stream
+#define ZV_LDR(slot, aptr, boff)                                                                                      \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[slot][nt] = *(const half8 *)(bp_ + (boff) + nt * 1024);  \
+    }
+#define ZV_MF(slot, SW, Z)                                \
+    mfma_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);      \
+    __builtin_amdgcn_sched_barrier(0);
+        // one tap: steps 0, 1 | wait for the next chunk, barrier, request the chunk three ahead | steps 2, 3 (which already
+        // read the next tap's first fragments)
+#define ZV_TAP(SW, Z0, tapstride)                                                                         \
+    {                                                                                                     \
+        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
+        ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
+        ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
+        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if (g + 3 < nchunk) issue(g + 3);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ap += (tapstride);                                                                                \
+        bp_ = bn_;                                                                                        \
+        ZV_LDR(0, ap, 0) ZV_MF(2, SW, false)                                                              \
+        ZV_LDR(1, ap + 32, 2 * 1024) ZV_MF(3, SW, false)                                                  \
+        g++;                                                                                              \
+    }
+        // ---- conv1 (dilated), transposed product
+        if (P.dbg & 2)
+        {
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
+            // keep the weight stream's protocol (barriers, requests) without the MFMAs
+            for (int tap = 0; tap < K; tap++)
+            {
+                if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + 3 < nchunk) issue(g + 3);
+                g++;
+            }
+        }
+        else
+        {
+            const char *ap = abase;
+            {
+                const char *bp_ = bl;
+                ZV_LDR(0, ap, 0)
+                ZV_LDR(1, ap + 32, 2 * 1024)
+            }
+            ZV_TAP(true, true, dil * RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
+        }
+        // every wave is done reading X: its LDS region becomes XT (raw barriers here: __syncthreads would drain the weight
+        // stream, whose next chunks are in flight under the pack)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
+        {
+            const int hh = lane >> 5;
+            const float sl = P.slope;
+            const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + nt * 32 + 8 * q + 4 * hh);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                {
+                    const int i = wave * 32 * MT + mt * 32 + (lane & 31);
+                    const int t = t0 - h2 + i;
+                    const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        uint2 pk = lrelu4_f16(acc[mt][nt][4 * q + 0] + bq[q].x, acc[mt][nt][4 * q + 1] + bq[q].y,
+                                              acc[mt][nt][4 * q + 2] + bq[q].z, acc[mt][nt][4 * q + 3] + bq[q].w, sl);
+                        if (edge)
+                        {
+                            pk.x = in ? pk.x : 0u;
+                            pk.y = in ? pk.y : 0u;
+                        }
+                        *(uint2 *)(smem + i * RS + (nt * 32 + 8 * q + 4 * hh) * 2) = pk;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
+        if (P.dbg & 2)
+        {
+            for (int tap = 0; tap < K; tap++)
+            {
+                if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + 3 < nchunk) issue(g + 3);
+                g++;
+            }
+        }
+        else
+        {
+            const char *ap = abase;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+                ZV_LDR(1, ap + 32, 2 * 1024)
+            }
+            ZV_TAP(false, true, RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
+        }
+#undef ZV_TAP
+#undef ZV_MF
+#undef ZV_LDR
+
+        // ---- epilogue: out = y + (conv2 + b2); descriptors over exactly this tile's valid rows (see resblock_pair_kernel)
+        if (P.dbg & 4) return;
+        if constexpr (MERGE) load_res();
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+        {
+            const int oc = nt * 32 + (lane & 31);
+            const float bias = P.b2[oc];
+            const int voff = voff0 + nt * 128;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+            {
+                if (P.dbg & 16) continue;
+                if constexpr (MERGE)
+                {
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const float v = (acc[mt][nt][r] + bias) + resv[mt][nt][r];
+                        msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
+                    }
+                    if (jb == jobs.njobs - 1)
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(msum[mt][nt][r]), rs_out, voff,
+                                                                  (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+                }
+                else
+                {
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[mt][nt][r]), rs_out, voff,
+                                                              (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0);
+                }
+            }
+        }
+    }
+}
+
+template <bool MERGE>
+static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
+{
+    constexpr int BM = 256;
+    const int TMmin = BM - (Kmax - 1);
+    dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);
+    // operand rows: BM + (K - 1) * dil, + dil: the last tap's prefetch reads one tap past the end
+    js.ring_off = round_up((BM + Kmax * dmax) * (64 * 2 + 16), 1024);
+    const size_t lds = (size_t)js.ring_off + 4 * 8192;
+    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    auto kern = resblock_pair64_kernel<MERGE>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+    return hipGetLastError();
+}
+
 // the MFMA loop of the fused kernels walks whole 8-step bodies (CP = 64: also half a body at the end) and at least one
 bool pair_supported(int Cp, int K)
 {
@@ -1057,6 +1382,19 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // measured (batch of 32 x 1 024 frames): once a launch has many rounds of workgroups the 128-channel stage is
     // bound by the weight stream from L2 (1 KiB of B fragment per 2 MFMAs per wave at MT = 2) and BM = 128 is 14 % faster;
     // the 64-channel stage does not care (-1 %).  The tile height never changes an output bit.
+    // 64 channels, batches: the form with the weights through an LDS ring (ZV_PAIR64_RING = 0 never, 2 whenever it fits)
+    {
+        const char *ring_s = getenv("ZV_PAIR64_RING");      // read per launch: tests switch it between models
+        const int ring_env = ring_s ? atoi(ring_s) : 1;
+        bool ok = Cp == 64 && ring_env != 0 && Kmax >= 3 && (256 + Kmax * dmax) * 144 + 4 * 8192 + 1024 <= 80 * 1024;
+        for (int i = 0; i < njobs && ok; i++) ok = jobs[i].w1r && jobs[i].w2r;
+        const long rwgs = (long)((Lmax + 256 - Kmax) / (257 - Kmax)) * segs.nseg * njobs;
+        if (ok && (ring_env == 2 || rwgs >= 6L * n_cu))
+        {
+            js.kmax = Kmax;
+            return merge_out ? launch_pair64_ring<true>(s, js, njobs, Lmax, Kmax, dmax) : launch_pair64_ring<false>(s, js, njobs, Lmax, Kmax, dmax);
+        }
+    }
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
     if (mt_env == 2 || mt_env == 4) MT = mt_env;
     js.kmax = Kmax;
@@ -1298,24 +1636,6 @@ __device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *
 #undef ZV_LD
 }
 
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
-// f16(lrelu(x + b)) of four values: packed add / multiply / convert (v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32: the
-// same IEEE results as the scalar forms), max(x, x*slope) as in lrelu_max
-__device__ __forceinline__ uint2 lrelu4_f16(float x0, float x1, float x2, float x3, float sl)
-{
-    const float2v a = {x0, x1}, c = {x2, x3};
-    const float2v as = a * sl, cs = c * sl;
-    const float2v ra = {lrelu_max_pre(a[0], as[0]), lrelu_max_pre(a[1], as[1])};
-    const float2v rc = {lrelu_max_pre(c[0], cs[0]), lrelu_max_pre(c[1], cs[1])};
-    const half2v ha = __builtin_convertvector(ra, half2v), hc = __builtin_convertvector(rc, half2v);
-    uint2 pk;
-    pk.x = *(const unsigned int *)&ha;
-    pk.y = *(const unsigned int *)&hc;
-    return pk;
-}
-
 // (A variant with Y in the transposed accumulator layout — both convs with the weights as the A operand, 8-byte operand
 // writes, 16-byte tile loads / stores: half the vector instructions — measured 7 % SLOWER: a 16-byte access per lane in
 // that layout touches 32 rows x 32 bytes per instruction, against 2 rows x 128 bytes for the 4-byte column accesses.)
@@ -1487,7 +1807,8 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
-    static const int cfg_env = getenv("ZV_TRIPLE_CFG") ? atoi(getenv("ZV_TRIPLE_CFG")) : 0;      // A/B hook: MT*1000 + R
+    const char *cfg_s = getenv("ZV_TRIPLE_CFG");
+    const int cfg_env = cfg_s ? atoi(cfg_s) : 0;      // A/B hook: MT*1000 + R
     TripleJobs js;
     js.segs = segs;
     js.rate = rate;
@@ -1515,7 +1836,8 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(round_up(gx, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
     // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always (A/B, tests)
-    static const int v2_env = getenv("ZV_TRIPLE_V2") ? atoi(getenv("ZV_TRIPLE_V2")) : 1;
+    const char *v2_s = getenv("ZV_TRIPLE_V2");           // read per launch: tests switch it between models
+    const int v2_env = v2_s ? atoi(v2_s) : 1;
     if (MT == 2 && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
     {
         size_t lds2 = 0;

@@ -139,6 +139,7 @@ struct PairJob
     const float *y;          // [L][Cp] f32
     float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
     const void  *w1, *w2;    // packed by pack_pair_weight (zero-padded per-tile segments)
+    const void  *w1r, *w2r;  // packed by pack_pair_weight_ring ([tap][kc][ntile] fragments), or null
     const float *b1, *b2;
     int          L, Cp, K, dil;
     float        slope;
@@ -155,12 +156,16 @@ struct PairJobs
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
     float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
+    int     ring_off;            // resblock_pair64_kernel: byte offset of the weight ring in LDS (set by the launcher)
 };
 // true when a ResBlock conv pair with Cp (padded) channels and K taps can run on the fused kernel
 bool       pair_supported(int Cp, int K);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
+// the same weight as the stream resblock_pair64_kernel moves through its LDS ring: [tap][kc][ntile][lane][8 halfs]
+size_t     pair_ring_weight_halfs(int Cp, int K);
+void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
 // merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
 // stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);

@@ -245,6 +245,14 @@ Model::Model(const std::string &path, int dev) : device(dev)
                         pack_pair_weight((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, pk.data());
                         *dst[q] = dev_alloc(pk.size() * 2 + 8192);
                         ZV_HIP(hipMemcpy(*dst[q], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+                        if (rp.c1.Cout_p == 64)
+                        {
+                            std::vector<uint16_t> rk(pair_ring_weight_halfs(64, rp.c1.K));
+                            pack_pair_weight_ring((const uint16_t *)g.get(nm).data, rp.c1.K, C, 64, rk.data());
+                            void **rd = q ? &rp.r2 : &rp.r1;
+                            *rd = dev_alloc(rk.size() * 2);
+                            ZV_HIP(hipMemcpy(*rd, rk.data(), rk.size() * 2, hipMemcpyHostToDevice));
+                        }
                     }
                 }
                 if (i == 0 && d == 0) hp.voc_resblock_kernels[j] = rp.c1.K;
@@ -917,6 +925,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav)
                 p.out = yout;
                 p.w1 = rp.p1;
                 p.w2 = rp.p2;
+                p.w1r = rp.r1;
+                p.w2r = rp.r2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
                 p.Cp = Cp;
