@@ -1074,6 +1074,15 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
 
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.z;
+    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
+    {
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 9] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+    }
+#endif
+    ZV_STAMP(0)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char *ring = smem + jobs.ring_off;
     const int tid = threadIdx.x;
@@ -1129,7 +1138,9 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
                         resv[mt][nt][r] = (P.dbg & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff0 + nt * 128, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
         };
         if constexpr (!MERGE) load_res();      // (the merged form holds the branches' running sum: it loads in the epilogue)
+        ZV_STAMP(1)
         __syncthreads();                                // X complete; the barrier drains the first three chunks too
+        ZV_STAMP(2)
 
         floatx16 acc[MT][NT];
         half8 a[4][MT], b[4][NT];
@@ -1150,9 +1161,10 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
         const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
         ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
         ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
+        if (!(P.dbg & 64)) {                                                                              \
         if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-        __builtin_amdgcn_s_barrier();                                                                     \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                           \
+        if (!(P.dbg & 128)) __builtin_amdgcn_s_barrier();                                                 \
         if (g + 3 < nchunk) issue(g + 3);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         ap += (tapstride);                                                                                \
@@ -1191,11 +1203,13 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
             ZV_TAP(true, true, dil * RS)
             for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
         }
+        ZV_STAMP(3)
         // every wave is done reading X: its LDS region becomes XT (raw barriers here: __syncthreads would drain the weight
         // stream, whose next chunks are in flight under the pack)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
+        ZV_STAMP(4)
         // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
         {
             const int hh = lane >> 5;
@@ -1231,6 +1245,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
+        ZV_STAMP(5)
         // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
         if (P.dbg & 2)
         {
@@ -1259,6 +1274,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 #undef ZV_LDR
 
         // ---- epilogue: out = y + (conv2 + b2); descriptors over exactly this tile's valid rows (see resblock_pair_kernel)
+        ZV_STAMP(6)
         if (P.dbg & 4) return;
         if constexpr (MERGE) load_res();
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
@@ -1295,6 +1311,10 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
                 }
             }
         }
+#ifdef ZV_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ZV_STAMP(7)
     }
 }
 
@@ -1644,7 +1664,11 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
 {
     constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    const TripleJob &P = jobs.j[blockIdx.z];
+    // workgroup -> (job, tile): with `il` jobs interleaved the MRF branches of one stretch of the sequence run next to each
+    // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM
+    const int il = jobs.interleave;
+    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const TripleJob &P = jobs.j[il > 1 ? (blockIdx.x >> 3) % il : blockIdx.z];
     const int K = P.K, nd = P.n_dil;
     const int h2 = (K - 1) / 2;
     int sumd = 0, dmax = 1;
@@ -1652,7 +1676,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
     const int H = h2 * (sumd + nd);
     const int TM = R - 2 * H;
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
     if (vt >= tps * jobs.segs.nseg) return;
     const int useg = vt / tps;
     const Seg sg = seg_at(jobs.segs, useg);
@@ -1812,6 +1836,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     TripleJobs js;
     js.segs = segs;
     js.rate = rate;
+    js.interleave = 1;
     // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are enough rows
     // for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
     const int Lmax = segs.max_rows * rate;
@@ -1852,10 +1877,13 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         }
         if (lds2 <= 80 * 1024)
         {
+            const char *il_s = getenv("ZV_TRIPLE_INTERLEAVE");
+            js.interleave = (il_s ? atoi(il_s) != 0 : true) ? njobs : 1;
+            const dim3 grid2 = js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid;
             auto launch = [&](auto kern, int nth) {
                 hipError_t e = lds2 > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) : hipSuccess;
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kern, grid, dim3(nth), lds2, s, js);
+                hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
             return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);

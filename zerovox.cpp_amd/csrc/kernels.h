@@ -191,6 +191,7 @@ struct TripleJobs
     TripleJob j[PAIR_MAX_JOBS];
     Segs      segs;
     int       rate;
+    int       interleave;        // resblock_block32_kernel: > 1 = that many jobs share grid.x, interleaved per XCD
 };
 // true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
 bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
