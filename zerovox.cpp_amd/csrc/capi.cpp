@@ -304,13 +304,16 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
 }
 
 // copies the finished waveforms out of the pinned staging block, on a few threads when there is enough to move
-static void scatter_out(const char *pin_wav, const size_t *off, float *const *wav, const uint32_t *T, size_t hop, uint32_t a, uint32_t b)
+static void scatter_out(const char *pin_wav, const size_t *off, float *const *wav, const uint32_t *T, size_t hop, uint32_t a, uint32_t b,
+                        uint32_t off_base = ~0u)
 {
+    if (off_base == ~0u) off_base = a;           // off[] is indexed from the first utterance of the launch group
+    off -= 0;
     size_t total = 0;
     for (uint32_t u = a; u < b; u++) total += (size_t)T[u] * hop * 4;
     const unsigned nth = total > ((size_t)8 << 20) ? 4u : 1u;
     auto work = [&](unsigned k) {
-        for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u - a], (size_t)T[u] * hop * 4);
+        for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u - off_base], (size_t)T[u] * hop * 4);
     };
     if (nth == 1)
     {
@@ -403,13 +406,52 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
                     t0 += t;
                 }
             }
-            M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
             int32_t *h_nf = (int32_t *)(pin + b_in);
             char *h_wav = pin + b_in + b_nf;
-            ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
-            ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
-            M.sync();
-            scatter_out(h_wav, woff.data(), wav, T, hop, a, b);
+            // Large batches: the last vocoder stage (two thirds of a waveform's bytes are produced there) runs in G groups of
+            // utterances; a finished group's waveforms travel to the host on a second stream and are copied out of the
+            // pinned block while the next group's kernels run.  Same kernels on the same rows: same bits.
+            const int G = (M.tail_groups() > 1 && bt.nseg >= 2 * M.tail_groups() && wav_bytes >= ((size_t)16 << 20) && !M.profiling && M.dbg_layer.kind < 0)
+                              ? M.tail_groups() : 1;
+            if (G <= 1)
+            {
+                M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
+                ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+                ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
+                M.sync();
+                scatter_out(h_wav, woff.data(), wav, T, hop, a, b);
+            }
+            else
+            {
+                M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
+                ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+                // contiguous groups of about wav_bytes / G each
+                std::vector<uint32_t> gb(G + 1, b);
+                gb[0] = a;
+                for (int g = 1; g < G; g++)
+                {
+                    uint32_t u = gb[g - 1] + 1;
+                    while (u < b && woff[u - a] < wav_bytes * g / G) u++;
+                    gb[g] = std::min(u, b - (uint32_t)(G - g));
+                }
+                hipStream_t cs = M.copy_stream();
+                for (int g = 0; g < G; g++)
+                {
+                    const uint32_t u0 = gb[g], u1 = gb[g + 1];
+                    M.vocode_tail(bt, d_mel, d_wav, (int)(u0 - a), (int)(u1 - u0));
+                    const size_t o0 = woff[u0 - a], o1 = u1 < b ? woff[u1 - a] : wav_bytes;
+                    ZV_HIP(hipEventRecord(M.tail_event(2 * g), M.stream));
+                    ZV_HIP(hipStreamWaitEvent(cs, M.tail_event(2 * g), 0));
+                    ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
+                    ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
+                }
+                for (int g = 0; g < G; g++)
+                {
+                    ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
+                    scatter_out(h_wav, woff.data(), wav, T, hop, gb[g], gb[g + 1], a);
+                }
+                M.sync();
+            }
             if (n_frames)
                 for (uint32_t u = a; u < b; u++) n_frames[u] = (uint32_t)h_nf[u - a];
             a = b;

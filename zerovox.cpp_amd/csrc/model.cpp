@@ -147,6 +147,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
     force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
     no_merge_ = getenv("ZV_NO_MERGE") && atoi(getenv("ZV_NO_MERGE")) != 0;
     voc_group_ = getenv("ZV_VOC_GROUP") ? atoi(getenv("ZV_VOC_GROUP")) : 0;
+    tail_groups_ = getenv("ZV_TAIL_GROUPS") ? atoi(getenv("ZV_TAIL_GROUPS")) : 4;
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
     lanes_[0].stream = stream;
@@ -450,6 +451,8 @@ Model::~Model()
     prof_clear();
     for (void *p : allocs_) hipFree(p);
     if (pinned_) hipHostFree(pinned_);
+    for (hipEvent_t e : tail_events_) hipEventDestroy(e);
+    if (copy_stream_) hipStreamDestroy(copy_stream_);
     for (Lane &l : lanes_)
     {
         if (l.arena.base) hipFree(l.arena.base);
@@ -459,6 +462,23 @@ Model::~Model()
 }
 
 void Model::sync() { ZV_HIP(hipStreamSynchronize(stream)); }
+
+hipStream_t Model::copy_stream()
+{
+    if (!copy_stream_) ZV_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    return copy_stream_;
+}
+
+hipEvent_t Model::tail_event(int i)
+{
+    while ((int)tail_events_.size() <= i)
+    {
+        hipEvent_t e;
+        ZV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        tail_events_.push_back(e);
+    }
+    return tail_events_[i];
+}
 
 uint32_t Model::vocoder_halo_frames() const
 {
@@ -675,6 +695,7 @@ void Model::group_end(const char *name)
 #define ZV_LAUNCH(name, bytes, flops, call)          \
     do                                               \
     {                                                \
+        if (skip_launch_) break;                     \
         hipEvent_t _e0;                              \
         tick(name, bytes, flops, &_e0);              \
         ZV_HIP(call);                                \
@@ -759,8 +780,19 @@ void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
     vocode_group(bt, d_mel, d_wav);
 }
 
-void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav)
+void Model::vocode_tail(const Batch &bt, const float *d_mel, float *d_wav, int g0, int cnt)
 {
+    if (!bt.d_frm || g0 < 0 || cnt < 1 || g0 + cnt > bt.nseg) fail(ZV_ERR_ARG, "internal: bad segment group");
+    Batch sub = bt;
+    sub.d_frm = bt.d_frm + g0;
+    sub.nseg = cnt;
+    vocode_group(sub, d_mel, d_wav, 2);
+}
+
+void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int part)
+{
+    struct Unskip { bool &f; ~Unskip() { f = false; } } unskip{skip_launch_};
+    skip_launch_ = part == 2;
     arena_require(arena_bytes_for(1, bt.t_rows, bt.nseg));
     arena_.used = 0;
     const Segs fr = bt.frames();
@@ -804,6 +836,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav)
     const float *prev_merged = nullptr;          // the previous stage stored (y0 + y1) + y2 instead of the three branches
     for (int i = 0; i < voc_.n_up; i++)
     {
+        const bool last_stage = i == voc_.n_up - 1;
+        skip_launch_ = (part == 1 && last_stage) || (part == 2 && !last_stage);
         const int s = voc_.scales[i];
         const ConvW &up = voc_.ups[i];
         const int Cout = C >> 1, Cp = round_up(Cout, 16);
@@ -969,6 +1003,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav)
     }
 
     // V3: (sum of branches)/3 -> leaky_relu(0.01) -> conv k7 (C -> 1) + b -> tanh          (:315-345)
+    skip_launch_ = part == 1;
     {
         OutConvArgs a;
         a.x0 = prev_merged ? prev_merged : prev_y[0];
@@ -1044,13 +1079,14 @@ template <typename F> void Model::run_captured(int kind, const Batch &b, const v
 }
 
 void Model::chain_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles, float *d_hidden,
-                      float *d_mel, float *d_wav, int32_t *d_nframes, const void *h2d_src, void *h2d_dst, size_t h2d_bytes)
+                      float *d_mel, float *d_wav, int32_t *d_nframes, const void *h2d_src, void *h2d_dst, size_t h2d_bytes, int voc_part)
 {
     auto run = [&]() {
         if (h2d_bytes) ZV_HIP(hipMemcpyAsync(h2d_dst, h2d_src, h2d_bytes, hipMemcpyHostToDevice, stream));
         encode_dev(b, d_ids, d_puncts, d_styles, d_hidden, d_nframes);
         decode_dev(b, d_hidden, d_styles, d_mel);        // the reference vocodes all T frames (src/zerovox.cpp:326-334)
-        vocode_dev(b, d_mel, d_wav);
+        if (voc_part == 1) vocode_group(b, d_mel, d_wav, 1);      // the caller runs the last stage in utterance groups
+        else vocode_dev(b, d_mel, d_wav);
     };
     if (!graph_mode || profiling)
     {
@@ -1058,7 +1094,7 @@ void Model::chain_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_pun
         return;
     }
     const void *key[8] = {d_ids, d_puncts, d_styles, d_hidden, d_mel, d_wav, d_nframes, h2d_src};
-    run_captured(1, b, key, 8, run);
+    run_captured(voc_part == 1 ? 2 : 1, b, key, 8, run);
 }
 
 void Model::vocode_dev_graph(const Batch &b, const float *d_mel, float *d_wav)

@@ -98,7 +98,15 @@ class Model
     // every tensor is the row concatenation over the batch: mel [t_rows][M], wav [t_rows * hop], hidden [t_rows][E],
     // ids / puncts [n_rows], styles [nseg][E]
     void vocode_dev(const Batch &b, const float *d_mel, float *d_wav);
-    void vocode_group(const Batch &b, const float *d_mel, float *d_wav);
+    // part: 0 = the whole schedule, 1 = everything before the last upsample stage, 2 = the last stage + output conv
+    void vocode_group(const Batch &b, const float *d_mel, float *d_wav, int part = 0);
+    // the tail (part 2) of segments [g0, g0 + cnt) of a batch whose head chain_dev(..., voc_part = 1) has enqueued: same
+    // arena layout, same row ranges, same bits as the unsplit schedule
+    void vocode_tail(const Batch &b, const float *d_mel, float *d_wav, int g0, int cnt);
+    // second stream + events for the waveform download of a finished group under the next group's kernels
+    hipStream_t copy_stream();
+    hipEvent_t  tail_event(int i);
+    int         tail_groups() const { return tail_groups_; }
     void decode_dev(const Batch &b, const float *d_hidden, const float *d_styles, float *d_mel);
     // taps are device pointers inside the arena (token rows as in ids), valid until the next call;
     // n_frames [nseg] is written to d_nframes (outside the arena)
@@ -156,7 +164,7 @@ class Model
     // h2d_src / h2d_dst / h2d_bytes (optional): an input upload that becomes the first node of the schedule
     void chain_dev(const Batch &b, const int32_t *d_ids, const int32_t *d_puncts, const float *d_styles, float *d_hidden,
                    float *d_mel, float *d_wav, int32_t *d_nframes, const void *h2d_src = nullptr, void *h2d_dst = nullptr,
-                   size_t h2d_bytes = 0);
+                   size_t h2d_bytes = 0, int voc_part = 0);
 
     // profiling (HIP events around every launch while enabled)
     bool profiling = false;
@@ -265,6 +273,10 @@ class Model
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
     int  voc_group_ = 0;          // ZV_VOC_GROUP=G: utterances per vocoder pass of a batch (0 = all at once)
+    int  tail_groups_ = 4;        // ZV_TAIL_GROUPS=G: utterance groups of a batch's last vocoder stage (0 / 1 = no split)
+    bool skip_launch_ = false;    // vocode_group: the launches of the part that is not asked for are skipped
+    hipStream_t copy_stream_ = nullptr;
+    std::vector<hipEvent_t> tail_events_;
     bool no_merge_ = false;       // ZV_NO_MERGE=1: the last dilation pair of a stage stores its three branch outputs instead of their sum (A/B, tests)
     bool force_fuse256_ = false;  // ZV_FUSE256=1: fused kernel for the 256-channel stage at any length (tests: the path
                                   // long / batched utterances take, exercised at sizes the CPU oracle can check)
