@@ -33,6 +33,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 static constexpr int CK_MAX = 256;
+// 16-byte pieces a thread keeps in flight while it stages a tile (10 — one round trip for every small tile — measured no
+// faster on the batch's upsample convs and costs the MT = 1 kernels a wave of occupancy)
 #ifndef ZV_STAGE_U
 #define ZV_STAGE_U 4
 #endif
@@ -209,7 +211,7 @@ __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *sme
         case PRO_NORM_ACT: stage_tile_p<U, PRO_NORM_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         case PRO_MELNORM: stage_tile_p<U, PRO_MELNORM, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
         case PRO_SCALE_ACT: stage_tile_p<U, PRO_SCALE_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
-        default: stage_tile_p<U, PRO_SUM3_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;
+        default: stage_tile_p<(U > 4 ? 4 : U), PRO_SUM3_ACT, NTH>(J, smem, RS, c0, ck, row_t0, rows, tid); break;   // three tensors per piece
     }
 }
 
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     // every staging load of the tile is in flight before the first one is consumed (one HBM round trip instead of one
     // per batch of four: measured 6.7 of a workgroup's 20.5 us at 64 channels)
     // (the merged variant holds the running sum of the branches: it keeps the short batches and its occupancy)
-    constexpr int STAGE_U = MERGE ? ZV_STAGE_U : ((CP == 32) ? 10 : (CP == 64 ? 12 : ZV_STAGE_U));
+    constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : 4));
     // (the wide stages keep their registers for occupancy: their first fragments are requested right before the loops)
     constexpr bool EARLY_B = CP <= 64 && !MERGE;
     half8 bw[4][NT];

@@ -837,7 +837,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
     for (int i = 0; i < voc_.n_up; i++)
     {
         const bool last_stage = i == voc_.n_up - 1;
-        skip_launch_ = (part == 1 && last_stage) || (part == 2 && !last_stage);
+        skip_launch_ = part == 2;                 // the head runs every upsample conv, the last stage's too (whole batch)
         const int s = voc_.scales[i];
         const ConvW &up = voc_.ups[i];
         const int Cout = C >> 1, Cp = round_up(Cout, 16);
@@ -863,6 +863,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             conv(&j, 1, fr, rate, "voc_upsample", 4.0 * La * C * (i == 0 ? 1 : 3) + 4.0 * La * s * Cout + 2.0 * C * Cout * 2 * s,
                  2.0 * La * C * Cout * 2 * s);
         }
+        skip_launch_ = (part == 1 && last_stage) || (part == 2 && !last_stage);
         L = Lo;
         La *= s;
         rate *= s;

@@ -98,7 +98,8 @@ class Model
     // every tensor is the row concatenation over the batch: mel [t_rows][M], wav [t_rows * hop], hidden [t_rows][E],
     // ids / puncts [n_rows], styles [nseg][E]
     void vocode_dev(const Batch &b, const float *d_mel, float *d_wav);
-    // part: 0 = the whole schedule, 1 = everything before the last upsample stage, 2 = the last stage + output conv
+    // part: 0 = the whole schedule, 1 = everything up to and including the last stage's upsample conv, 2 = the last
+    // stage's residual blocks + the output conv
     void vocode_group(const Batch &b, const float *d_mel, float *d_wav, int part = 0);
     // the tail (part 2) of segments [g0, g0 + cnt) of a batch whose head chain_dev(..., voc_part = 1) has enqueued: same
     // arena layout, same row ranges, same bits as the unsplit schedule
