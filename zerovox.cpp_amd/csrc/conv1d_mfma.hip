@@ -449,6 +449,20 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
 #undef ZV_UN8
 }
 
+// ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
+// stamps the clock at its phase boundaries into a buffer of its own (cdna_hip_programming.md §7, in-kernel stamps)
+#ifdef ZV_STAMPS
+constexpr int ZV_STAMP_WGS = 1 << 17, ZV_STAMP_N = 12;
+__device__ unsigned long long zv_stamp_buf[(size_t)ZV_STAMP_WGS * ZV_STAMP_N];
+#define ZV_STAMP(k)                                                                                   \
+    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)                                    \
+    {                                                                                                 \
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + (k)] = __builtin_amdgcn_s_memrealtime();         \
+    }
+#else
+#define ZV_STAMP(k)
+#endif
+
 // f64 partial sums of a wave's 32 x 32 output tile per channel (= lane & 31): the lane's 16 rows in register order, then
 // the two half-waves (rows 4*(lane>>5) + ...); rows at or past L do not count.  See launch_stats_finalize.
 __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_first, int L, double *dst)
@@ -469,6 +483,9 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 
 // Each wave owns (32*MT) rows x (32*NT) output channels: NT = 2 halves the LDS reads per MFMA (an A fragment feeds two
 // MFMAs) and lets a workgroup cover 256 output channels, so a wide conv stages its input half as often.
+// (Measured dead end, round 2: the staged tile double-buffered in LDS and filled by LDS-DMA while the MFMA loop of the
+// previous chunk runs.  hipcc answers an LDS-DMA in flight with vmcnt(0) waits on the B-fragment stream of the MFMA
+// loop — the counted waits that keep eight fragments in flight are gone — and the wide decoder convs ran 3 % slower.)
 template <int MT, int WN, int NT>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
@@ -526,12 +543,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
 
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.y;
+    int stamp_k = 1;
+#endif
+    ZV_STAMP(0)
     for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
         if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         __syncthreads();
+#ifdef ZV_STAMPS
+        if (stamp_k < 10) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
         if (n_ok && !(J.dbg & 2))
         {
             const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
@@ -547,6 +572,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
             else
                 mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
         }
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
     }
 
     // ---------------- epilogue ----------------
@@ -603,6 +631,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
             }
         }
     }
+#ifdef ZV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZV_STAMP(11)
+#endif
 }
 
 template <int MT, int WN, int NT>
@@ -613,6 +645,9 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     const int ntiles = (Cout_p + 31) / 32;
     jobs.tps = (Lmax + BM - 1) / BM;
     dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN * NT - 1) / (WN * NT), njobs);
+#ifdef ZV_STAMPS
+    jobs.stamp = getenv("ZV_STAMP_CONV") && atoi(getenv("ZV_STAMP_CONV")) == (int)grid.y && jobs.j[0].Cin_p >= 1024 && njobs == 1;
+#endif
     const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv1d_mfma_kernel<MT, WN, NT>;
@@ -788,20 +823,6 @@ __device__ __forceinline__ uint2 lrelu4_f16(float x0, float x1, float x2, float 
     return pk;
 }
 
-
-// ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
-// stamps the clock at its phase boundaries into a buffer of its own (cdna_hip_programming.md §7, in-kernel stamps)
-#ifdef ZV_STAMPS
-constexpr int ZV_STAMP_WGS = 1 << 17, ZV_STAMP_N = 12;
-__device__ unsigned long long zv_stamp_buf[(size_t)ZV_STAMP_WGS * ZV_STAMP_N];
-#define ZV_STAMP(k)                                                                                   \
-    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)                                    \
-    {                                                                                                 \
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + (k)] = __builtin_amdgcn_s_memrealtime();         \
-    }
-#else
-#define ZV_STAMP(k)
-#endif
 
 // Stage f16(lrelu(y)) rows through a buffer descriptor: rows outside [0, L) are out of the descriptor's range and
 // read as 0 (= the conv's zero padding, lrelu(0) = 0) with no per-row predicate; CP is a power of two so the

@@ -119,6 +119,9 @@ struct ConvJobs
     Segs    segs;
     int     rate;                // rows per base row of this launch
     int     tps;                 // row tiles per segment (grid.x = tps * nseg)
+#ifdef ZV_STAMPS
+    int     stamp;               // diagnostic build: this launch writes phase stamps
+#endif
 };
 
 // bytes of one packed conv weight: [ntile32][chunk][tap][kc][lane 64][8 halfs]
