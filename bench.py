@@ -49,7 +49,7 @@ MFMA_PEAK_TF = 2500.0          # dense f16 MFMA peak (same guide)
 UTTS_PER_GPU = 32
 FRAMES = 1024
 SEED_W, SEED_BATCH = 1234, 3
-TRAFFIC_PROFILE = "profiles/r02_resblock_traffic.json"
+TRAFFIC_PROFILE = "profiles/r02_v2_resblock_traffic.json"
 
 
 def main():
@@ -182,13 +182,15 @@ def main():
                 traffic = None
         tf = rb["algo_flops"] / (rb["total_ms"] * 1e-3) / 1e12
         roofline = {"bound": "hbm",
-                    "kernel": "HiFi-GAN ResBlock Conv1d launches of the batch (resblock_pair_kernel<256|128|64,2> x3 each, "
-                              "resblock_triple_kernel<32,2,512> x1 per pass; every launch covers all utterances)",
+                    "kernel": "HiFi-GAN ResBlock Conv1d launches of the batch (resblock_pair_kernel<256,2> x3, <128,4> x3, "
+                              "resblock_pair64_kernel x3, resblock_block32_kernel<2,512> x1 per pass; every launch covers all "
+                              "utterances; in the timed region the last one runs as 4 launches of 8 utterances each)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_is": "ALGORITHMIC bytes of the unfused 72-conv formulation (SURVEY.md §8d) / launch time / 8 TB/s; "
                                "the fused kernels move fewer real bytes (see traffic) and the wide stages are MFMA-bound",
                     "traffic": traffic, "traffic_source": traffic_src, "traffic_GBps_in_that_profile": traffic_gbps,
+                    "traffic_frac_of_peak_in_that_profile": round(traffic_gbps / HBM_PEAK_GBS, 4) if traffic_gbps else None,
                     "algo_bytes_per_launch": rb["algo_bytes"] / rb["launches"],
                     "avg_launch_us": round(avg_us, 2), "launches_per_step": rb["launches"] // psteps,
                     "mfma_TFLOPs": round(tf, 1), "mfma_frac_of_dense_f16_peak": round(tf / MFMA_PEAK_TF, 4),
@@ -286,7 +288,8 @@ def main():
             "vs_baseline": None, "dtype": "f16*f16->f32 (MFMA) convs, f32 (MFMA) attention/linear, f32 activations", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[3]%s: per GPU a batch of %d mixed-length utterances (32..256 phonemes), "
                                    "T = %d frames each, full fs2encoder -> stylettsdec -> hifigan, host ids in / host wav out "
-                                   "(H2D + D2H inside the timed region), one launch per kernel for the whole batch, %s" %
+                                   "(H2D + D2H inside the timed region), one launch per kernel for the whole batch (the last vocoder stage's residual "
+                                   "blocks + output conv in 4 utterance groups, each group's waveform download under the next group's kernels), %s" %
                                    (" x %d GPUs = configs[4]" % world if world > 1 else "", len(utts), T,
                                     "eager launches" if args.no_graph else "hipGraph replay"),
                        "utterances_per_gpu": len(utts), "utterances_total": n_global, "frames": T,

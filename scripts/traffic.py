@@ -5,7 +5,7 @@ family's launches, with the launch durations of the kernel trace of the same bui
 usage: traffic.py <pmc.txt> <kernel_trace_summary.txt> <tag>"""
 import json, re, sys
 pmc, trace, tag = sys.argv[1:4]
-fam = ("resblock_pair_kernel", "resblock_triple_kernel")
+fam = ("resblock_pair_kernel", "resblock_pair64_kernel", "resblock_triple_kernel", "resblock_block32_kernel")
 fetch, write, n = {}, {}, {}
 sect = None
 for ln in open(pmc):
