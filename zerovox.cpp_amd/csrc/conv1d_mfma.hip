@@ -1682,6 +1682,20 @@ __device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *
 // (A variant with Y in the transposed accumulator layout — both convs with the weights as the A operand, 8-byte operand
 // writes, 16-byte tile loads / stores: half the vector instructions — measured 7 % SLOWER: a 16-byte access per lane in
 // that layout touches 32 rows x 32 bytes per instruction, against 2 rows x 128 bytes for the 4-byte column accesses.)
+// LDS stores the compiler does not see as LDS stores: hipcc orders every visible LDS access behind an LDS-DMA in flight with
+// s_waitcnt vmcnt(0), which would drain the weight stream at the first operand write of every phase.  The hazards these
+// stores do have (against the other waves' reads) are covered by the kernel's own barriers and lgkmcnt waits.
+template <int OFF>
+__device__ __forceinline__ void lds_st_b64(unsigned addr, uint2 v)
+{
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_st_b16(unsigned addr, _Float16 h)
+{
+    asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(addr), "v"(h), "n"(OFF) : "memory");
+}
+
 template <int MT, int R>
 __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel(const TripleJobs jobs)
 {
@@ -1714,15 +1728,34 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
     const int nb = ((K * NKC + 3) >> 2) >> 1;         // 8-step bodies per conv
     const int nblk = 8 * nb;                          // weight fragments per conv (real ones first, zero blocks behind)
 
+    // Two weight buffers where they fit (jobs.db_mask: 3- and 7-tap branches): a conv's fragments are requested while the
+    // conv BEFORE it runs and have a whole MFMA loop plus a pack / epilogue phase to land.  With one buffer (11 taps) the
+    // request can only follow the barrier that ends the previous conv and the next barrier waits for it: phase stamps of
+    // that form show 2 us of DMA latency in each of a block's six pack / epilogue phases (27.6 us per workgroup).
+    // The biases of the block's six convs sit in LDS, so nothing in the loop below waits on the vector-memory counter but
+    // the barriers that are meant to.
+    const bool db = (jobs.db_mask >> (il > 1 ? (blockIdx.x >> 3) % il : blockIdx.z)) & 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char *wlds = smem + round_up(xrows * RS, 1024);
+    char *wlds2 = db ? wlds + nblk * 1024 : wlds;                  // conv2's weights
+    float *blds = (float *)(wlds + (db ? 2 : 1) * nblk * 1024 + 2048);      // behind the last-prefetch slack: [d][conv][32]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31;
     const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
 
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x;
+    int stamp_k = 1;
+#endif
+    ZV_STAMP(0)
     dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
+    if (tid < 64 * nd)
+    {
+        const int d_ = tid >> 6, c_ = tid & 31;
+        blds[tid] = (tid & 32) ? P.b2[d_][c_] : P.b1[d_][c_];
+    }
     // the margins of the operand region stay zero for the whole kernel: rows [0, XM) and [XM + R, xrows)
     {
         const int lo = XM * RS / 16, hi0 = (XM + R) * RS / 16, hi = xrows * RS / 16;
@@ -1742,26 +1775,63 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
     }
 
     const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-    const char *wl = wlds + lane * 16;
+    const char *wl = wlds + lane * 16, *wl2 = wlds2 + lane * 16;
     const float sl = P.slope;
     for (int d = 0; d < nd; d++)
     {
         const int dil = P.dil[d], h1 = h2 * dil;
         if (d)
         {
-            __syncthreads();                   // the previous conv2 is done reading XT and its weights
-            dma_weights32(P.w1[d], wlds, nblk, wave, lane, NWV);
+            // the previous conv2 is done reading XT and its weights (raw barrier: conv1's weights may be in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!db) dma_weights32(P.w1[d], wlds, nblk, wave, lane, NWV);
         }
         // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
         {
-            char *xp = smem + (XM + irow0) * RS + col * 2;
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    *(_Float16 *)(xp + (mt * 32 + (r & 3) + 8 * (r >> 2)) * RS) = (_Float16)lrelu_max(yreg[mt][r], sl);
+            static_assert(MT == 2, "the operand writes below are written out for two row tiles per wave");
+            const unsigned xa = (unsigned)(uintptr_t)(smem + (XM + irow0) * RS + col * 2);
+#define ZV_XW(mt, r) lds_st_b16<((mt) * 32 + ((r) & 3) + 8 * ((r) >> 2)) * RS>(xa, (_Float16)lrelu_max(yreg[mt][r], sl));
+            ZV_XW(0, 0)
+            ZV_XW(0, 1)
+            ZV_XW(0, 2)
+            ZV_XW(0, 3)
+            ZV_XW(0, 4)
+            ZV_XW(0, 5)
+            ZV_XW(0, 6)
+            ZV_XW(0, 7)
+            ZV_XW(0, 8)
+            ZV_XW(0, 9)
+            ZV_XW(0, 10)
+            ZV_XW(0, 11)
+            ZV_XW(0, 12)
+            ZV_XW(0, 13)
+            ZV_XW(0, 14)
+            ZV_XW(0, 15)
+            ZV_XW(1, 0)
+            ZV_XW(1, 1)
+            ZV_XW(1, 2)
+            ZV_XW(1, 3)
+            ZV_XW(1, 4)
+            ZV_XW(1, 5)
+            ZV_XW(1, 6)
+            ZV_XW(1, 7)
+            ZV_XW(1, 8)
+            ZV_XW(1, 9)
+            ZV_XW(1, 10)
+            ZV_XW(1, 11)
+            ZV_XW(1, 12)
+            ZV_XW(1, 13)
+            ZV_XW(1, 14)
+            ZV_XW(1, 15)
+#undef ZV_XW
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __syncthreads();                       // X complete, conv1's weights landed (the barrier drains the DMA)
+        if (db) dma_weights32(P.w2[d], wlds2, nblk, wave, lane, NWV);      // under conv1 and the pack
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
 
         // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
         floatx16 acc[MT][1];
@@ -1771,14 +1841,29 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
         if (!(P.dbg & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, nb);
-        __syncthreads();                       // every wave is done reading X and conv1's weights
-        dma_weights32(P.w2[d], wlds, nblk, wave, lane, NWV);
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
+        // every wave is done reading X and conv1's weights (raw barrier: conv2's weights may be in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // (the biases are read before any request goes out: hipcc orders an LDS read behind a pending LDS-DMA with vmcnt(0))
+        // (raw ds_reads: hipcc would order a visible LDS read behind the weight DMA in flight with vmcnt(0) and drain it here)
+        float4 bq[4];
+        float bias2;
+        {
+            const unsigned ba = (unsigned)(uintptr_t)(blds + d * 64 + 4 * (lane >> 5)), bb = (unsigned)(uintptr_t)(blds + d * 64 + 32 + col);
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:32\n\tds_read_b128 %2, %5 offset:64\n\t"
+                         "ds_read_b128 %3, %5 offset:96\n\tds_read_b32 %4, %6\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bias2)
+                         : "v"(ba), "v"(bb)
+                         : "memory");
+        }
+        if (!db) dma_weights32(P.w2[d], wlds, nblk, wave, lane, NWV);
         // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L)
         {
             const int hh = lane >> 5;
-            float4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1[d] + 8 * q + 4 * hh);
+            const unsigned pa = (unsigned)(uintptr_t)(smem + (XM + wave * 32 * MT + (lane & 31)) * RS + 4 * hh * 2);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
             {
@@ -1795,16 +1880,34 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
                         pk.x = in ? pk.x : 0u;
                         pk.y = in ? pk.y : 0u;
                     }
-                    *(uint2 *)(smem + (XM + i) * RS + (8 * q + 4 * hh) * 2) = pk;
+                    if (mt == 0)
+                    {
+                        if (q == 0) lds_st_b64<0>(pa, pk);
+                        if (q == 1) lds_st_b64<16>(pa, pk);
+                        if (q == 2) lds_st_b64<32>(pa, pk);
+                        if (q == 3) lds_st_b64<48>(pa, pk);
+                    }
+                    else
+                    {
+                        if (q == 0) lds_st_b64<32 * RS>(pa, pk);
+                        if (q == 1) lds_st_b64<32 * RS + 16>(pa, pk);
+                        if (q == 2) lds_st_b64<32 * RS + 32>(pa, pk);
+                        if (q == 3) lds_st_b64<32 * RS + 48>(pa, pk);
+                    }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __syncthreads();                       // XT complete, conv2's weights landed
+        if (db && d + 1 < nd) dma_weights32(P.w1[d + 1], wlds, nblk, wave, lane, NWV);      // under conv2, the update and the next X write
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl, nb);
+        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, nb);
         {
-            const float bias = P.b2[d][col];
+            const float bias = bias2;
             if (edge)
             {
 #pragma unroll
@@ -1840,6 +1943,10 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
             const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, 0);
         }
+#ifdef ZV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZV_STAMP(11)
+#endif
 }
 
 bool triple_supported(int Cp, int K, const int *dil, int n_dil)
@@ -1860,6 +1967,10 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     js.segs = segs;
     js.rate = rate;
     js.interleave = 1;
+    js.db_mask = 0;
+#ifdef ZV_STAMPS
+    js.stamp = getenv("ZV_STAMP_CP") && atoi(getenv("ZV_STAMP_CP")) == 32;
+#endif
     // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are enough rows
     // for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
     const int Lmax = segs.max_rows * rate;
@@ -1889,6 +2000,8 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     if (MT == 2 && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
     {
         size_t lds2 = 0;
+        const char *db_s = getenv("ZV_TRIPLE_DB");          // read per launch (A/B): 0 = one weight buffer for every branch
+        js.db_mask = 0;
         for (int i = 0; i < njobs; i++)
         {
             const TripleJob &P = jobs[i];
@@ -1896,7 +2009,11 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
             for (int d = 0; d < P.n_dil; d++) dmax = P.dil[d] > dmax ? P.dil[d] : dmax;
             const size_t rows = R + 2 * ((P.K - 1) / 2) * dmax + 5 * dmax;
             const int nb = ((P.K * 2 + 3) >> 2) >> 1;
-            lds2 = std::max(lds2, (size_t)round_up((int)(rows * 80), 1024) + (size_t)(8 * nb + 2) * 1024);   // + 2 fragments: the last B prefetch
+            // operand tile + weight buffer(s) + 2 fragments (the last B prefetch) + the block's biases
+            const size_t one = (size_t)round_up((int)(rows * 80), 1024) + (size_t)(8 * nb + 2) * 1024 + 1024;
+            const bool db = (db_s ? atoi(db_s) != 0 : true) && one + (size_t)8 * nb * 1024 <= 80 * 1024;
+            if (db) js.db_mask |= 1 << i;
+            lds2 = std::max(lds2, one + (db ? (size_t)8 * nb * 1024 : 0));
         }
         if (lds2 <= 80 * 1024)
         {

@@ -195,6 +195,10 @@ struct TripleJobs
     Segs      segs;
     int       rate;
     int       interleave;        // resblock_block32_kernel: > 1 = that many jobs share grid.x, interleaved per XCD
+    int       db_mask;           // resblock_block32_kernel: bit j = job j keeps two weight buffers in LDS (set by the launcher)
+#ifdef ZV_STAMPS
+    int       stamp;
+#endif
 };
 // true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
 bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
