@@ -449,6 +449,64 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
 #undef ZV_UN8
 }
 
+// The MFMA loop of a full 256-channel chunk for single-utterance launches (MT row tiles x ONE output tile per wave, one
+// wave per SIMD, at most a round of workgroups: registers are free, latency is everything).  A step is MT MFMAs — 32
+// cycles at MT = 1 — so the loops above, whose A fragment is requested one step ahead (an LDS round trip per step) and
+// whose weight fragments 4-8 steps ahead (an L2 round trip per 4 steps), take 75 ns per step (phase stamps: 3.6 us per
+// chunk for 0.8 us of matrix work).  Here one body = one tap = 16 steps, every address an immediate off the body's base,
+// the A fragments travel 6 steps ahead through a ring of 8 register sets and the weight fragments 16 steps ahead through
+// a ring of 16 that is carried from chunk to chunk (the generic layout puts the next chunk's first tap right behind this
+// chunk's last: the caller preloads the ring once, before the first tile is even staged; the last tap's requests run up
+// to 16 KiB past the chunk — load_conv / load_upsample allocate that slack).  Same step order as mfma_taps<256> /
+// mfma_chunk — tap-major, 16 channels per step — hence the same bits.  (Measured: 2.8 us per chunk, 1.7 us where the
+// weights hit L2; a conv of 33 us becomes 29.6 us.  What is left is the cold weights — every row tile of a channel group
+// misses on them together — and the staging round trips between the loops.)
+template <int MT>
+__device__ __forceinline__ void preload_ring16(half8 (&b)[16], const half8 *wq)
+{
+#pragma unroll
+    for (int u = 0; u < 16; u++) b[u] = wq[u * 64];
+}
+
+template <int MT>
+__device__ __forceinline__ void mfma_taps_single256(floatx16 (&acc)[MT][1], const char *ap, int dilRS, const half8 *wq, int K,
+                                                    half8 (&b)[16])
+{
+    constexpr int RS = 256 * 2 + 16;
+    half8 a[8][MT];
+#define ZV_SA(un) (((un) >= 16 ? apn : ap) + ((un) & 15) * 32)
+#define ZV_SLOAD(un)                                                                              \
+    {                                                                                             \
+        const char *np_ = ZV_SA(un);                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) & 7][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+    }
+#define ZV_SSTEP(u)                                                                               \
+    {                                                                                             \
+        half8 ac_[MT];                                                                            \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) ac_[mt] = a[(u) & 7][mt];               \
+        ZV_SLOAD((u) + 6)                                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                         \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac_[mt], b[u], acc[mt][0], 0, 0, 0); \
+        b[u] = wq[(16 + (u)) * 64];                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    }
+    {
+        const char *apn = ap;
+        ZV_SLOAD(0) ZV_SLOAD(1) ZV_SLOAD(2) ZV_SLOAD(3) ZV_SLOAD(4) ZV_SLOAD(5)
+    }
+    for (int tap = 0; tap < K; tap++)
+    {
+        const char *apn = ap + dilRS;
+        ZV_SSTEP(0) ZV_SSTEP(1) ZV_SSTEP(2) ZV_SSTEP(3) ZV_SSTEP(4) ZV_SSTEP(5) ZV_SSTEP(6) ZV_SSTEP(7)
+        ZV_SSTEP(8) ZV_SSTEP(9) ZV_SSTEP(10) ZV_SSTEP(11) ZV_SSTEP(12) ZV_SSTEP(13) ZV_SSTEP(14) ZV_SSTEP(15)
+        ap = apn;
+        wq += 16 * 64;
+    }
+#undef ZV_SSTEP
+#undef ZV_SLOAD
+#undef ZV_SA
+}
+
 // ---- diagnostic build only (-DZV_STAMPS, never the shipped library): wave 0 of a workgroup of the fused pair kernel
 // stamps the clock at its phase boundaries into a buffer of its own (cdna_hip_programming.md §7, in-kernel stamps)
 #ifdef ZV_STAMPS
@@ -486,7 +544,7 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 // (Measured dead end, round 2: the staged tile double-buffered in LDS and filled by LDS-DMA while the MFMA loop of the
 // previous chunk runs.  hipcc answers an LDS-DMA in flight with vmcnt(0) waits on the B-fragment stream of the MFMA
 // loop — the counted waits that keep eight fragments in flight are gone — and the wide decoder convs ran 3 % slower.)
-template <int MT, int WN, int NT>
+template <int MT, int WN, int NT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
@@ -543,6 +601,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
 
+    // SINGLE: the weight ring of the full 256-channel chunks, requested before the first tile is staged
+    half8 bring[SINGLE ? 16 : 1];
+    const bool single256 = SINGLE && NT == 1 && J.ck == 256 && Cin_p >= 256 && n_ok;
+    if constexpr (SINGLE)
+        if (single256) preload_ring16<MT>(bring, (const half8 *)J.w + (size_t)ntl * K * nicb * 64 + lane);
 #ifdef ZV_STAMPS
     const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.y;
     int stamp_k = 1;
@@ -563,7 +626,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
             const size_t wseg = (size_t)K * nicb * 64;             // half8 units between consecutive output tiles
             // full chunks of 256 / 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there
             // and the blocks of a chunk are contiguous [tap][kc]: exactly the order mfma_taps walks)
-            if (ck == 256 && J.ck == 256)
+            if constexpr (SINGLE && NT == 1)
+            {
+                if (ck == 256 && single256)
+                    mfma_taps_single256<MT>(acc, abase, dil * RS, wp, K, bring);
+                else
+                    mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
+            }
+            else if (ck == 256 && J.ck == 256)
                 mfma_taps<256, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
             else if (ck == 128 && J.ck == 128)
                 mfma_taps<128, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
@@ -637,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
 #endif
 }
 
-template <int MT, int WN, int NT>
+template <int MT, int WN, int NT, bool SINGLE = false>
 static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int halo, int ck, int dmax_)
 {
     constexpr int WM = 4 / WN;
@@ -650,7 +720,7 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
 #endif
     const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_mfma_kernel<MT, WN, NT>;
+    auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -720,6 +790,16 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
     int NT = (WN == 4 && ntiles >= 8 && MT >= 2 && wgs(MT, 2) >= 4L * n_cu) ? 2 : 1;
     if (nt_env == 1 || (nt_env == 2 && WN == 4 && ntiles >= 2 && MT >= 2)) NT = nt_env;
     if (NT == 2 && MT == 4) MT = 2;        // 64 x 64 per wave: the 128 x 64 shape does not fit 256 registers
+    {
+        // single-utterance launches (at most a round of workgroups, one wave per SIMD): the deep-lookahead loop for the
+        // 256-channel chunks
+        const char *de = getenv("ZV_CONV_SINGLE");         // read per launch (A/B, tests)
+        if ((de ? atoi(de) != 0 : true) && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= (long)n_cu)
+        {
+            if (WN == 4) return launch_cfg<1, 4, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
+            if (WN == 2) return launch_cfg<1, 2, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
+        }
+    }
 #define ZV_CASE(mt, wn, nt) \
     if (MT == mt && WN == wn && NT == nt) return launch_cfg<mt, wn, nt>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
     ZV_CASE(4, 4, 1) ZV_CASE(2, 4, 1) ZV_CASE(1, 4, 1) ZV_CASE(2, 4, 2)

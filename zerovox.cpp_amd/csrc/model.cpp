@@ -58,7 +58,7 @@ ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::s
     c.ck = conv_pick_ck(c.Cin_p);
     std::vector<uint16_t> packed(packed_conv_weight_halfs(c.Cin_p, c.Cout_p, c.K));
     pack_conv_weight((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
-    c.w = dev_alloc(packed.size() * 2 + 16384);      // slack: the MFMA loop prefetches up to 12 KiB past the last block
+    c.w = dev_alloc(packed.size() * 2 + 32768);      // slack: the MFMA loops request up to 16 KiB past the last block
     ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     if (!bname.empty())
     {
@@ -120,7 +120,7 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
                 }
     std::vector<uint16_t> packed(packed_conv_weight_halfs(c.Cin_p, c.Cout_p, c.K));
     pack_conv_weight(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
-    c.w = dev_alloc(packed.size() * 2 + 16384);
+    c.w = dev_alloc(packed.size() * 2 + 32768);      // slack: as in load_conv
     ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
     snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.b", idx);
     const GgufTensor &b = g.get(nm);
