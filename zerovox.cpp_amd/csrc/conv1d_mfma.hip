@@ -794,7 +794,7 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
         // single-utterance launches (at most a round of workgroups, one wave per SIMD): the deep-lookahead loop for the
         // 256-channel chunks
         const char *de = getenv("ZV_CONV_SINGLE");         // read per launch (A/B, tests)
-        if ((de ? atoi(de) != 0 : true) && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= (long)n_cu)
+        if ((de ? atoi(de) != 0 : true) && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= 2L * n_cu)
         {
             if (WN == 4) return launch_cfg<1, 4, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
             if (WN == 2) return launch_cfg<1, 2, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
