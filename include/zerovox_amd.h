@@ -119,7 +119,10 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
  * calls (no batch padding: padding would change the numbers, SURVEY Appx C-H2).  Up to 64 utterances / 64 Ki frames go
  * through the three stages as ONE launch per kernel: tensors are row-concatenated over the group and a segment table in
  * HBM tells every kernel where each utterance begins and ends, so the launches have many rounds of workgroups and the
- * whole group — input upload included — is one hipGraph (captured once per capacity bucket when graph mode is on).
+ * whole group — input upload included — is one hipGraph (captured once per capacity bucket when graph mode is on).  For a
+ * large group the graph ends before the last vocoder stage's residual blocks: those and the output conv run in four
+ * utterance sub-groups and a finished sub-group's waveforms are copied to the host (second stream) and into wav[] while
+ * the next one computes; wav[u] is complete when the call returns, as before.
  * BASELINE.json configs[3]/[4]; with several GPUs the caller shards the list (one model per GPU, no collective). */
 zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
                               const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T,
