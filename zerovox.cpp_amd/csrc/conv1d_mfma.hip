@@ -1455,8 +1455,10 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
     dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);      // multiple of 8: zv_xcd_tile
-    // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil
-    const size_t lds = (size_t)(BM + (Kmax + 4) * dmax) * (CP * 2 + 16);
+    // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil.  The loop walks
+    // whole taps once a tap is at least a body (CP >= 128): K + 1 taps (51 KB for the 128-channel stage: room for three
+    // workgroups per CU instead of two — measured worth 0.6 %)
+    const size_t lds = (size_t)(BM + (Kmax + (CP >= 128 ? 1 : 4)) * dmax) * (CP * 2 + 16);
     auto kern = resblock_pair_kernel<CP, MT, MERGE>;
     if (lds > 64 * 1024)
     {
