@@ -128,6 +128,19 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
                               const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T,
                               float *const *wav, uint32_t *n_frames);
 
+/* The two halves of zv_synthesize_batch for a serving loop that keeps a batch in flight per lane (additive):
+ * _begin builds the input block, enqueues the upload, the kernels and the waveform downloads of ONE launch group (at most
+ * 64 utterances / 64 Ki frames of capacity, else ZV_ERR_ARG) on lane `lane` (< ZV_BATCH_LANES; each lane owns a stream, an
+ * activation arena and a pinned staging block) and returns; _end waits for that batch and fills wav[] / n_frames[], which
+ * — like T[] and the pointer arrays' targets — must stay valid until then.  While one lane's last kernels and downloads
+ * run, the next lane's upload and first kernels already do.  Results are those of zv_synthesize_batch, bit for bit.
+ * Every other entry point may be called in between (they use lane 0's stream: not while lane 0 has a batch in flight). */
+#define ZV_BATCH_LANES 4
+zv_status zv_synthesize_batch_begin(zv_model *m, uint32_t lane, uint32_t n_utt, const int32_t *const *ids,
+                                    const int32_t *const *puncts, const float *const *styles, const uint32_t *n_phonemes,
+                                    const uint32_t *T, float *const *wav, uint32_t *n_frames);
+zv_status zv_synthesize_batch_end(zv_model *m, uint32_t lane);
+
 /* longest single utterance in frames (buffer descriptors address one utterance with 32-bit byte offsets; at most
  * 32768 frames = 7.4 min of audio).  Longer T returns ZV_ERR_ARG; zv_vocode_stream has no such limit on the total. */
 uint32_t  zv_max_frames(const zv_model *m);

@@ -221,6 +221,56 @@ def test_ragged_batches_equal_stand_alone_calls(models):
         assert nf == rnf and np.array_equal(w, rw)
 
 
+def test_batches_in_flight_on_two_lanes_equal_the_synchronous_call(models):
+    """zv_synthesize_batch_begin / _end: a serving loop that keeps a batch in flight per lane (the next batch's upload and
+    kernels start while the previous one's tail downloads) must return, for every batch, the bits of zv_synthesize_batch;
+    large batches (tail groups + copy stream) and small ones, eager and graph replay; misuse is an error, not a hang"""
+    from zerovox_cpp_amd import capi, synth
+    model, g, tensors = models("medium")
+    rng = np.random.default_rng(9)
+    batches = []
+    for b in range(3):
+        utts = []
+        for u in range(16):
+            n = int(rng.integers(24, 96))
+            ids, puncts, style = synth.encoder_inputs(g, 1300 + 16 * b + u, n)
+            utts.append((ids, puncts, style, int(rng.integers(900, 1025))))      # > 16 MB of waveforms: four tail groups
+        batches.append(utts)
+    small = [(*synth.encoder_inputs(g, 1400 + u, 20 + u), 64 + u) for u in range(5)]
+    batches.append(small)
+    ref = [model.synthesize_batch(b) for b in batches]
+    for graph in (False, True):
+        model.set_graph_mode(graph)
+        try:
+            calls = [model.prepare_batch(b) for b in batches]
+            order = [0, 1, 2, 3, 0, 2]
+            got = {}
+            prev = None
+            for k, bi in enumerate(order):
+                lane = k % 2
+                calls[bi].begin(lane)
+                if prev is not None:
+                    calls[prev[0]].end(prev[1])
+                    got[prev[0]] = [(w.copy(), nf) for w, nf in calls[prev[0]].results()]
+                prev = (bi, lane)
+            calls[prev[0]].end(prev[1])
+            got[prev[0]] = [(w.copy(), nf) for w, nf in calls[prev[0]].results()]
+        finally:
+            model.set_graph_mode(False)
+        for bi, res in got.items():
+            for (w, nf), (rw, rnf) in zip(res, ref[bi]):
+                assert nf == rnf and np.array_equal(w, rw), (graph, bi)
+    c = model.prepare_batch(small)
+    with pytest.raises(capi.ZvError):
+        c.end(1)                                   # nothing in flight on that lane
+    c.begin(1)
+    with pytest.raises(capi.ZvError):
+        c.begin(1)                                 # the lane is taken
+    c.end(1)
+    with pytest.raises(capi.ZvError):
+        c.begin(capi.BATCH_LANES)                  # no such lane
+
+
 def test_two_rank_sharded_bench_equals_single_process_batch(tmp_path):
     """the N > 1 path of bench.py (one process per rank, contiguous shards of the global utterance list, no data-path
     collective) rehearsed on ONE GPU: two ranks via torch.distributed.run + gloo, both on cuda:0 (ZV_BENCH_ONE_GPU).

@@ -17,13 +17,14 @@ LIB_PATH = os.environ.get("ZEROVOX_AMD_LIB") or os.path.join(HERE, "libzerovox_a
 # every symbol include/zerovox_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
-    "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_device_alloc", "zv_device_free",
+    "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_synthesize_batch_begin", "zv_synthesize_batch_end", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
     "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance", "zv_debug_layer",
 ]
 
 
 WAV_SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.c_uint64)
+BATCH_LANES = 4      # ZV_BATCH_LANES of include/zerovox_amd.h
 
 
 class HParams(C.Structure):
@@ -78,6 +79,9 @@ def load_library(path: Optional[str] = None):
     lib.zv_synthesize.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
     lib.zv_synthesize_batch.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32),
                                         C.POINTER(vp), C.POINTER(u32)]
+    lib.zv_synthesize_batch_begin.argtypes = [vp, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32),
+                                              C.POINTER(vp), C.POINTER(u32)]
+    lib.zv_synthesize_batch_end.argtypes = [vp, u32]
     lib.zv_device_alloc.argtypes = [vp, C.c_size_t]
     lib.zv_device_alloc.restype = vp
     lib.zv_device_free.argtypes = [vp, vp]
@@ -290,6 +294,15 @@ class BatchCall:
     def run(self):
         m = self.model
         m._chk(m.lib.zv_synthesize_batch(m.h, self.n, self.ids_p, self.pun_p, self.sty_p, self.Ns, self.Ts, self.wav_p, self.nf))
+
+    def begin(self, lane: int):
+        """zv_synthesize_batch_begin on `lane`: returns once everything is enqueued; results are valid after end(lane)"""
+        m = self.model
+        m._chk(m.lib.zv_synthesize_batch_begin(m.h, lane, self.n, self.ids_p, self.pun_p, self.sty_p, self.Ns, self.Ts, self.wav_p, self.nf))
+
+    def end(self, lane: int):
+        m = self.model
+        m._chk(m.lib.zv_synthesize_batch_end(m.h, lane))
 
     def results(self):
         return [(self.wavs[i], int(self.nf[i])) for i in range(self.n)]

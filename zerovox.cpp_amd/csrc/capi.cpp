@@ -11,10 +11,14 @@
 
 using zv::Model;
 
+struct PendingBatch;
 struct zv_model
 {
-    Model *m;
+    Model        *m;
+    PendingBatch *pending;       // [ZV_BATCH_LANES], see zv_synthesize_batch_begin
 };
+
+static void free_pending(zv_model *m);
 
 static thread_local std::string g_last_error;
 
@@ -56,13 +60,14 @@ zv_status zv_model_load(const char *gguf_path, int device, zv_model **out)
         ZV_NEED(gguf_path && out, "null argument");
         *out = nullptr;
         Model *m = new Model(gguf_path, device);
-        *out = new zv_model{m};
+        *out = new zv_model{m, nullptr};
     });
 }
 
 void zv_model_free(zv_model *m)
 {
     if (!m) return;
+    free_pending(m);
     delete m->m;
     delete m;
 }
@@ -326,6 +331,191 @@ static void scatter_out(const char *pin_wav, const size_t *off, float *const *wa
     for (auto &t : th) t.join();
 }
 
+// ---- batches.  One launch group (up to 64 utterances / 64 Ki frames) is enqueued on a lane — input block built in the
+// lane's pinned memory, the chain as one hipGraph, the last vocoder stage in utterance groups with each group's download
+// behind it on the lane's copy stream — and finished later: wait for the downloads, copy the waveforms out.  The
+// synchronous entry point is enqueue + finish on lane 0; zv_synthesize_batch_begin / _end expose the two halves so that a
+// caller can keep a batch in flight per lane (the next batch's upload and kernels run while this one's tail downloads).
+struct PendingBatch
+{
+    bool                  active = false;
+    uint32_t              n_utt = 0;
+    int                   G = 1;
+    std::vector<uint32_t> gb;          // group boundaries (utterance indices), G + 1 entries
+    std::vector<size_t>   woff;        // byte offset of each utterance's waveform in the pinned block
+    std::vector<uint32_t> T;
+    std::vector<float *>  wav;
+    uint32_t             *n_frames = nullptr;
+    const char           *h_wav = nullptr;
+    const int32_t        *h_nf = nullptr;
+    size_t                hop = 0;
+};
+static PendingBatch &pending_slot(zv_model *m, int lane)
+{
+    if (!m->pending) m->pending = new PendingBatch[ZV_BATCH_LANES];
+    return m->pending[lane];
+}
+static void free_pending(zv_model *m)
+{
+    delete[] m->pending;
+    m->pending = nullptr;
+}
+
+static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
+                          const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T, float *const *wav,
+                          uint32_t *n_frames)
+{
+    Model &M = *m->m;
+    PendingBatch &pb = pending_slot(m, lane);
+    if (pb.active) zv::fail(ZV_ERR_ARG, "lane %d already has a batch in flight", lane);
+    M.select_lane(lane);
+    const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    uint32_t nmax = 0, tmax = 0;
+    for (uint32_t u = 0; u < n_utt; u++)
+    {
+        nmax = std::max(nmax, n_phonemes[u]);
+        tmax = std::max(tmax, T[u]);
+    }
+    zv::Batch bt;
+    bt.nseg = (int)n_utt;
+    bt.n_max = zv::round_up((int)nmax, 32);
+    bt.t_max = zv::round_up((int)tmax, 64);
+    bt.n_rows = (size_t)bt.nseg * bt.n_max;
+    bt.t_rows = (size_t)bt.nseg * bt.t_max;
+    // device block: [frame counts][inputs: token table | frame table | ids | puncts | styles][hidden][mel][wav]
+    const size_t b_tab = al((size_t)bt.nseg * sizeof(zv::Seg)), b_ids = al(bt.n_rows * 4), b_sty = al((size_t)bt.nseg * E * 4);
+    const size_t b_in = 2 * b_tab + 2 * b_ids + b_sty;
+    const size_t b_nf = al((size_t)bt.nseg * 4), b_hid = al(bt.t_rows * E * 4), b_mel = al(bt.t_rows * Mm * 4),
+                 b_wav = al(bt.t_rows * hop * 4);
+    M.reserve_batch(bt);
+    char *io = (char *)M.io_scratch(b_nf + b_in + b_hid + b_mel + b_wav);
+    int32_t *d_nf = (int32_t *)io;
+    char *d_in = io + b_nf;
+    zv::Seg *d_tok = (zv::Seg *)d_in, *d_frm = (zv::Seg *)(d_in + b_tab);
+    int32_t *d_ids = (int32_t *)(d_in + 2 * b_tab), *d_pun = (int32_t *)(d_in + 2 * b_tab + b_ids);
+    float *d_sty = (float *)(d_in + 2 * b_tab + 2 * b_ids);
+    float *d_hid = (float *)(d_in + b_in), *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
+    bt.d_tok = d_tok;
+    bt.d_frm = d_frm;
+    // pinned mirror of the input block + landing area of the results
+    size_t wav_bytes = 0;
+    pb.woff.assign(n_utt, 0);
+    for (uint32_t u = 0; u < n_utt; u++)
+    {
+        pb.woff[u] = wav_bytes;
+        wav_bytes += (size_t)T[u] * hop * 4;
+    }
+    char *pin = (char *)M.pinned_scratch(b_in + b_nf + al(wav_bytes));
+    {
+        zv::Seg *h_tok = (zv::Seg *)pin, *h_frm = (zv::Seg *)(pin + b_tab);
+        int32_t *h_ids = (int32_t *)(pin + 2 * b_tab), *h_pun = (int32_t *)(pin + 2 * b_tab + b_ids);
+        float *h_sty = (float *)(pin + 2 * b_tab + 2 * b_ids);
+        int32_t n0 = 0, t0 = 0;
+        for (uint32_t u = 0; u < n_utt; u++)
+        {
+            const int32_t n = (int32_t)n_phonemes[u], t = (int32_t)T[u];
+            h_tok[u] = zv::Seg{n0, n, n, 0};
+            h_frm[u] = zv::Seg{t0, t, 0, 0};
+            memcpy(h_ids + n0, ids[u], (size_t)n * 4);
+            memcpy(h_pun + n0, puncts[u], (size_t)n * 4);
+            memcpy(h_sty + (size_t)u * E, styles[u], E * 4);
+            n0 += n;
+            t0 += t;
+        }
+    }
+    int32_t *h_nf = (int32_t *)(pin + b_in);
+    char *h_wav = pin + b_in + b_nf;
+    // Large batches: the last vocoder stage (two thirds of a waveform's bytes are produced there) runs in G groups of
+    // utterances; a finished group's waveforms travel to the host on the lane's copy stream while the next group's kernels
+    // run.  Same kernels on the same rows: same bits.
+    const int G = (M.tail_groups() > 1 && bt.nseg >= 2 * M.tail_groups() && wav_bytes >= ((size_t)16 << 20) && !M.profiling && M.dbg_layer.kind < 0)
+                      ? M.tail_groups() : 1;
+    hipStream_t cs = M.copy_stream();
+    pb.gb.assign(G + 1, n_utt);
+    pb.gb[0] = 0;
+    if (G <= 1)
+    {
+        M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
+        ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+        ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
+        ZV_HIP(hipEventRecord(M.tail_event(1), M.stream));
+    }
+    else
+    {
+        M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
+        ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+        for (int g = 1; g < G; g++)               // contiguous groups of about wav_bytes / G each
+        {
+            uint32_t u = pb.gb[g - 1] + 1;
+            while (u < n_utt && pb.woff[u] < wav_bytes * g / G) u++;
+            pb.gb[g] = std::min(u, n_utt - (uint32_t)(G - g));
+        }
+        for (int g = 0; g < G; g++)
+        {
+            const uint32_t u0 = pb.gb[g], u1 = pb.gb[g + 1];
+            M.vocode_tail(bt, d_mel, d_wav, (int)u0, (int)(u1 - u0));
+            const size_t o0 = pb.woff[u0], o1 = u1 < n_utt ? pb.woff[u1] : wav_bytes;
+            ZV_HIP(hipEventRecord(M.tail_event(2 * g), M.stream));
+            ZV_HIP(hipStreamWaitEvent(cs, M.tail_event(2 * g), 0));
+            ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
+            ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
+        }
+    }
+    pb.active = true;
+    pb.n_utt = n_utt;
+    pb.G = G;
+    pb.T.assign(T, T + n_utt);
+    pb.wav.assign(wav, wav + n_utt);
+    pb.n_frames = n_frames;
+    pb.h_wav = h_wav;
+    pb.h_nf = h_nf;
+    pb.hop = hop;
+}
+
+static void batch_finish(zv_model *m, int lane)
+{
+    Model &M = *m->m;
+    PendingBatch &pb = pending_slot(m, lane);
+    if (!pb.active) zv::fail(ZV_ERR_ARG, "lane %d has no batch in flight", lane);
+    M.select_lane(lane);
+    pb.active = false;
+    for (int g = 0; g < pb.G; g++)
+    {
+        ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
+        scatter_out(pb.h_wav, pb.woff.data(), pb.wav.data(), pb.T.data(), pb.hop, pb.gb[g], pb.gb[g + 1], 0);
+    }
+    M.sync();                                     // the frame counts (and, unsplit, the waveforms) travel on the lane's stream
+    if (pb.n_frames)
+        for (uint32_t u = 0; u < pb.n_utt; u++) pb.n_frames[u] = (uint32_t)pb.h_nf[u];
+}
+
+static void batch_check(Model &M, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts, const float *const *styles,
+                        const uint32_t *n_phonemes, const uint32_t *T, float *const *wav)
+{
+    for (uint32_t u = 0; u < n_utt; u++)
+    {
+        ZV_NEED(ids[u] && puncts[u] && styles[u] && wav[u], "null utterance pointer");
+        ZV_NEED(n_phonemes[u] > 0 && T[u] > 0, "n and T must be > 0");
+        check_T(M, T[u]);
+        check_ids(M, ids[u], puncts[u], n_phonemes[u]);
+    }
+}
+
+// how many utterances from `a` on form one launch group: up to 64 utterances / 64 Ki frames of capacity
+static uint32_t batch_group_end(uint32_t a, uint32_t n_utt, const uint32_t *T)
+{
+    uint32_t b = a, tmax = 0;
+    while (b < n_utt && b - a < 64)
+    {
+        const uint32_t tm = std::max(tmax, T[b]);
+        if (b > a && (uint64_t)(b - a + 1) * zv::round_up((int)tm, 64) > 65536) break;
+        tmax = tm;
+        b++;
+    }
+    return b;
+}
+
 zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
                               const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T, float *const *wav,
                               uint32_t *n_frames)
@@ -334,128 +524,44 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
         ZV_NEED(m && ids && puncts && styles && n_phonemes && T && wav, "null argument");
         Model &M = *m->m;
         ZV_HIP(hipSetDevice(M.device));
-        M.select_lane(0);
-        for (uint32_t u = 0; u < n_utt; u++)
-        {
-            ZV_NEED(ids[u] && puncts[u] && styles[u] && wav[u], "null utterance pointer");
-            ZV_NEED(n_phonemes[u] > 0 && T[u] > 0, "n and T must be > 0");
-            check_T(M, T[u]);
-            check_ids(M, ids[u], puncts[u], n_phonemes[u]);
-        }
-        const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
-        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        batch_check(M, n_utt, ids, puncts, styles, n_phonemes, T, wav);
         // Groups of up to 64 utterances / 64 Ki frames go through the chain as ONE launch per kernel: every tensor is
         // the row concatenation of the group, the segment tables tell the kernels where each utterance starts and ends.
         // Capacities are rounded up so that batches of similar shape replay the same captured graph.
         uint32_t a = 0;
         while (a < n_utt)
         {
-            uint32_t b = a, nmax = 0, tmax = 0;
-            while (b < n_utt && b - a < 64)
-            {
-                const uint32_t nm = std::max(nmax, n_phonemes[b]), tm = std::max(tmax, T[b]);
-                if (b > a && (uint64_t)(b - a + 1) * zv::round_up((int)tm, 64) > 65536) break;
-                nmax = nm;
-                tmax = tm;
-                b++;
-            }
-            zv::Batch bt;
-            bt.nseg = (int)(b - a);
-            bt.n_max = zv::round_up((int)nmax, 32);
-            bt.t_max = zv::round_up((int)tmax, 64);
-            bt.n_rows = (size_t)bt.nseg * bt.n_max;
-            bt.t_rows = (size_t)bt.nseg * bt.t_max;
-            // device block: [frame counts][inputs: token table | frame table | ids | puncts | styles][hidden][mel][wav]
-            const size_t b_tab = al((size_t)bt.nseg * sizeof(zv::Seg)), b_ids = al(bt.n_rows * 4), b_sty = al((size_t)bt.nseg * E * 4);
-            const size_t b_in = 2 * b_tab + 2 * b_ids + b_sty;
-            const size_t b_nf = al((size_t)bt.nseg * 4), b_hid = al(bt.t_rows * E * 4), b_mel = al(bt.t_rows * Mm * 4),
-                         b_wav = al(bt.t_rows * hop * 4);
-            M.reserve_batch(bt);
-            char *io = (char *)M.io_scratch(b_nf + b_in + b_hid + b_mel + b_wav);
-            int32_t *d_nf = (int32_t *)io;
-            char *d_in = io + b_nf;
-            zv::Seg *d_tok = (zv::Seg *)d_in, *d_frm = (zv::Seg *)(d_in + b_tab);
-            int32_t *d_ids = (int32_t *)(d_in + 2 * b_tab), *d_pun = (int32_t *)(d_in + 2 * b_tab + b_ids);
-            float *d_sty = (float *)(d_in + 2 * b_tab + 2 * b_ids);
-            float *d_hid = (float *)(d_in + b_in), *d_mel = (float *)((char *)d_hid + b_hid), *d_wav = (float *)((char *)d_mel + b_mel);
-            bt.d_tok = d_tok;
-            bt.d_frm = d_frm;
-            // pinned mirror of the input block + landing area of the results
-            size_t wav_bytes = 0;
-            std::vector<size_t> woff(bt.nseg);
-            for (uint32_t u = a; u < b; u++)
-            {
-                woff[u - a] = wav_bytes;
-                wav_bytes += (size_t)T[u] * hop * 4;
-            }
-            char *pin = (char *)M.pinned_scratch(b_in + b_nf + al(wav_bytes));
-            {
-                zv::Seg *h_tok = (zv::Seg *)pin, *h_frm = (zv::Seg *)(pin + b_tab);
-                int32_t *h_ids = (int32_t *)(pin + 2 * b_tab), *h_pun = (int32_t *)(pin + 2 * b_tab + b_ids);
-                float *h_sty = (float *)(pin + 2 * b_tab + 2 * b_ids);
-                int32_t n0 = 0, t0 = 0;
-                for (uint32_t u = a; u < b; u++)
-                {
-                    const int32_t n = (int32_t)n_phonemes[u], t = (int32_t)T[u];
-                    h_tok[u - a] = zv::Seg{n0, n, n, 0};
-                    h_frm[u - a] = zv::Seg{t0, t, 0, 0};
-                    memcpy(h_ids + n0, ids[u], (size_t)n * 4);
-                    memcpy(h_pun + n0, puncts[u], (size_t)n * 4);
-                    memcpy(h_sty + (size_t)(u - a) * E, styles[u], E * 4);
-                    n0 += n;
-                    t0 += t;
-                }
-            }
-            int32_t *h_nf = (int32_t *)(pin + b_in);
-            char *h_wav = pin + b_in + b_nf;
-            // Large batches: the last vocoder stage (two thirds of a waveform's bytes are produced there) runs in G groups of
-            // utterances; a finished group's waveforms travel to the host on a second stream and are copied out of the
-            // pinned block while the next group's kernels run.  Same kernels on the same rows: same bits.
-            const int G = (M.tail_groups() > 1 && bt.nseg >= 2 * M.tail_groups() && wav_bytes >= ((size_t)16 << 20) && !M.profiling && M.dbg_layer.kind < 0)
-                              ? M.tail_groups() : 1;
-            if (G <= 1)
-            {
-                M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
-                ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
-                ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
-                M.sync();
-                scatter_out(h_wav, woff.data(), wav, T, hop, a, b);
-            }
-            else
-            {
-                M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
-                ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
-                // contiguous groups of about wav_bytes / G each
-                std::vector<uint32_t> gb(G + 1, b);
-                gb[0] = a;
-                for (int g = 1; g < G; g++)
-                {
-                    uint32_t u = gb[g - 1] + 1;
-                    while (u < b && woff[u - a] < wav_bytes * g / G) u++;
-                    gb[g] = std::min(u, b - (uint32_t)(G - g));
-                }
-                hipStream_t cs = M.copy_stream();
-                for (int g = 0; g < G; g++)
-                {
-                    const uint32_t u0 = gb[g], u1 = gb[g + 1];
-                    M.vocode_tail(bt, d_mel, d_wav, (int)(u0 - a), (int)(u1 - u0));
-                    const size_t o0 = woff[u0 - a], o1 = u1 < b ? woff[u1 - a] : wav_bytes;
-                    ZV_HIP(hipEventRecord(M.tail_event(2 * g), M.stream));
-                    ZV_HIP(hipStreamWaitEvent(cs, M.tail_event(2 * g), 0));
-                    ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
-                    ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
-                }
-                for (int g = 0; g < G; g++)
-                {
-                    ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
-                    scatter_out(h_wav, woff.data(), wav, T, hop, gb[g], gb[g + 1], a);
-                }
-                M.sync();
-            }
-            if (n_frames)
-                for (uint32_t u = a; u < b; u++) n_frames[u] = (uint32_t)h_nf[u - a];
+            const uint32_t b = batch_group_end(a, n_utt, T);
+            batch_enqueue(m, 0, b - a, ids + a, puncts + a, styles + a, n_phonemes + a, T + a, wav + a, n_frames ? n_frames + a : nullptr);
+            batch_finish(m, 0);
             a = b;
         }
+    });
+}
+
+zv_status zv_synthesize_batch_begin(zv_model *m, uint32_t lane, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
+                                    const float *const *styles, const uint32_t *n_phonemes, const uint32_t *T, float *const *wav,
+                                    uint32_t *n_frames)
+{
+    return guarded([&] {
+        ZV_NEED(m && ids && puncts && styles && n_phonemes && T && wav, "null argument");
+        ZV_NEED(lane < ZV_BATCH_LANES, "lane out of range");
+        ZV_NEED(n_utt > 0, "empty batch");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        batch_check(M, n_utt, ids, puncts, styles, n_phonemes, T, wav);
+        ZV_NEED(batch_group_end(0, n_utt, T) == n_utt, "an asynchronous batch must fit one launch group (64 utterances, 64 Ki frames of capacity)");
+        batch_enqueue(m, (int)lane, n_utt, ids, puncts, styles, n_phonemes, T, wav, n_frames);
+    });
+}
+
+zv_status zv_synthesize_batch_end(zv_model *m, uint32_t lane)
+{
+    return guarded([&] {
+        ZV_NEED(m, "null argument");
+        ZV_NEED(lane < ZV_BATCH_LANES, "lane out of range");
+        ZV_HIP(hipSetDevice(m->m->device));
+        batch_finish(m, (int)lane);
     });
 }
 

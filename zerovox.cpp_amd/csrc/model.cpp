@@ -450,13 +450,20 @@ Model::~Model()
     drop_graphs();
     prof_clear();
     for (void *p : allocs_) hipFree(p);
-    if (pinned_) hipHostFree(pinned_);
-    for (hipEvent_t e : tail_events_) hipEventDestroy(e);
-    if (copy_stream_) hipStreamDestroy(copy_stream_);
+    if (lanes_.empty())
+    {
+        if (pinned_) hipHostFree(pinned_);
+        for (hipEvent_t e : tail_events_) hipEventDestroy(e);
+        if (copy_stream_) hipStreamDestroy(copy_stream_);
+    }
     for (Lane &l : lanes_)
     {
+        if (l.copy_stream) hipStreamSynchronize(l.copy_stream);
         if (l.arena.base) hipFree(l.arena.base);
         if (l.io) hipFree(l.io);
+        if (l.pinned) hipHostFree(l.pinned);
+        for (hipEvent_t e : l.tail_events) hipEventDestroy(e);
+        if (l.copy_stream) hipStreamDestroy(l.copy_stream);
         if (l.stream) hipStreamDestroy(l.stream);
     }
 }
@@ -507,6 +514,10 @@ void Model::stash_lane()
     l.arena = arena_;
     l.io = io_;
     l.io_cap = io_cap_;
+    l.pinned = pinned_;
+    l.pinned_cap = pinned_cap_;
+    l.copy_stream = copy_stream_;
+    l.tail_events = tail_events_;
 }
 
 void Model::select_lane(int i)
@@ -525,6 +536,10 @@ void Model::select_lane(int i)
     arena_ = lanes_[i].arena;
     io_ = lanes_[i].io;
     io_cap_ = lanes_[i].io_cap;
+    pinned_ = lanes_[i].pinned;
+    pinned_cap_ = lanes_[i].pinned_cap;
+    copy_stream_ = lanes_[i].copy_stream;
+    tail_events_ = lanes_[i].tail_events;
 }
 
 void Model::sync_all_lanes()
@@ -537,7 +552,8 @@ void *Model::pinned_scratch(size_t bytes)
 {
     if (bytes > pinned_cap_)
     {
-        sync_all_lanes();
+        ZV_HIP(hipStreamSynchronize(stream));            // the block belongs to this lane: only its streams use it
+        if (copy_stream_) ZV_HIP(hipStreamSynchronize(copy_stream_));
         if (pinned_) hipHostFree(pinned_);
         pinned_ = nullptr;
         pinned_cap_ = 0;
@@ -1027,6 +1043,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
 
 void Model::drop_graphs()
 {
+    sync_all_lanes();                            // an exec of another lane may still be running
     for (auto &g : graphs_)
         if (g.exec) hipGraphExecDestroy(g.exec);
     graphs_.clear();

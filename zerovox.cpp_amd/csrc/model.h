@@ -264,6 +264,11 @@ class Model
         DeviceArena arena;
         void       *io = nullptr;
         size_t      io_cap = 0;
+        // host staging block, download stream and events of the lane (a batch in flight per lane: zv_synthesize_batch_begin)
+        void       *pinned = nullptr;
+        size_t      pinned_cap = 0;
+        hipStream_t copy_stream = nullptr;
+        std::vector<hipEvent_t> tail_events;
     };
     std::vector<Lane> lanes_;
     void  *pinned_ = nullptr;
