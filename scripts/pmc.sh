@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 CNT="$1"; shift
 rm -rf /tmp/zvpmc && mkdir -p /tmp/zvpmc
-env "$@" rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/zvpmc -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-graph --no-extras > /tmp/zvpmc/bench.json 2>/tmp/zvpmc/err.txt
+env "$@" rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/zvpmc -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline > /tmp/zvpmc/bench.json 2>/tmp/zvpmc/err.txt
 python - <<'PY'
 import csv, glob, collections
 fs = glob.glob('/tmp/zvpmc/**/*counter_collection.csv', recursive=True)

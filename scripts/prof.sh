@@ -1,7 +1,7 @@
 # rocprofv3 kernel trace of the bench (eager launches) -> per-config summary on stdout
 export TMPDIR=/tmp
 rm -rf /tmp/zvprof && mkdir -p /tmp/zvprof
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zvprof -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-graph --no-extras > /tmp/zvprof/bench.json 2>/tmp/zvprof/err.txt
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zvprof -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-graph --no-extras --no-pipeline > /tmp/zvprof/bench.json 2>/tmp/zvprof/err.txt
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob('/tmp/zvprof/**/*kernel_trace.csv', recursive=True)[0]

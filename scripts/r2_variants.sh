@@ -5,7 +5,7 @@ mkdir -p $O
 for V in "$@"; do
   echo "== $V" >> $O/variants.txt
   rm -rf /tmp/zvkp
-  env $V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zvkp -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras > $O/vb.json 2>$O/vb.err || { tail -5 $O/vb.err >> $O/variants.txt; continue; }
+  env $V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/zvkp -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline > $O/vb.json 2>$O/vb.err || { tail -5 $O/vb.err >> $O/variants.txt; continue; }
   python - >> $O/variants.txt <<'PY'
 import csv, glob, collections
 f = glob.glob('/tmp/zvkp/**/*kernel_trace.csv', recursive=True)[0]
