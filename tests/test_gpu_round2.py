@@ -266,7 +266,10 @@ def test_batches_in_flight_on_two_lanes_equal_the_synchronous_call(models):
     c.begin(1)
     with pytest.raises(capi.ZvError):
         c.begin(1)                                 # the lane is taken
+    with pytest.raises(capi.ZvError):
+        model.vocode(np.zeros((8, g.num_mels), np.float32))      # a synchronous call would reuse the busy lane's buffers
     c.end(1)
+    assert model.vocode(np.zeros((8, g.num_mels), np.float32)).shape == (8 * g.hop_size,)
     with pytest.raises(capi.ZvError):
         c.begin(capi.BATCH_LANES)                  # no such lane
 

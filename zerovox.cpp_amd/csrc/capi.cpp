@@ -19,6 +19,7 @@ struct zv_model
 };
 
 static void free_pending(zv_model *m);
+static void need_idle(zv_model *m);      // fails when the lane the next call would run on has a batch in flight
 
 static thread_local std::string g_last_error;
 
@@ -133,6 +134,7 @@ zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts,
         ZV_NEED(n > 0, "n must be > 0");
         ZV_NEED(num_phonemes <= n, "num_phonemes exceeds n");
         Model &M = *m->m;
+        need_idle(m);
         check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         check_ids(M, ids, puncts, n);
@@ -174,6 +176,7 @@ zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32
     return guarded([&] {
         ZV_NEED(m && hidden && style && mel, "null argument");
         Model &M = *m->m;
+        need_idle(m);
         check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         const size_t E = M.E(), Mm = M.hp.audio_num_mels;
@@ -193,6 +196,7 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
     return guarded([&] {
         ZV_NEED(m && mel && wav, "null argument");
         Model &M = *m->m;
+        need_idle(m);
         check_T(M, T);
         ZV_HIP(hipSetDevice(M.device));
         const size_t b_mel = ((size_t)T * M.hp.audio_num_mels * 4 + 255) & ~(size_t)255, b_wav = (size_t)T * M.hp.audio_hop_size * 4;
@@ -213,6 +217,7 @@ zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t c
         ZV_NEED(m && mel && sink, "null argument");
         ZV_NEED(T > 0 && chunk_frames > 0, "T and chunk_frames must be > 0");
         Model &M = *m->m;
+        need_idle(m);
         ZV_HIP(hipSetDevice(M.device));
         M.select_lane(0);
         const size_t Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
@@ -299,6 +304,7 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
         ZV_NEED(m && ids && puncts && style && wav, "null argument");
         ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
         Model &M = *m->m;
+        need_idle(m);
         ZV_HIP(hipSetDevice(M.device));
         M.select_lane(0);
         int32_t nf = 0;
@@ -359,6 +365,12 @@ static void free_pending(zv_model *m)
 {
     delete[] m->pending;
     m->pending = nullptr;
+}
+static void need_idle(zv_model *m)
+{
+    const int l = m->m->current_lane();
+    if (m->pending && l < ZV_BATCH_LANES && m->pending[l].active)
+        zv::fail(ZV_ERR_ARG, "lane %d has a batch in flight (zv_synthesize_batch_begin): finish it with zv_synthesize_batch_end first", l);
 }
 
 static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
@@ -573,6 +585,7 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
         ZV_NEED(m && x && out, "null argument");
         ZV_NEED(rows > 0, "rows must be > 0");
         Model &M = *m->m;
+        need_idle(m);
         ZV_HIP(hipSetDevice(M.device));
         M.select_lane(0);
         ZV_NEED(!M.graph_mode, "zv_debug_layer runs eagerly: turn graph mode off");
