@@ -55,7 +55,7 @@ TRAFFIC_PROFILE = "profiles/r02_v2_resblock_traffic.json"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts-per-gpu", type=int, default=UTTS_PER_GPU)
     ap.add_argument("--frames", type=int, default=FRAMES)
@@ -119,7 +119,8 @@ def main():
     hop, sr = model.hp.audio_hop_size, model.hp.audio_sampling_rate
     model.set_graph_mode(not args.no_graph)
     call = model.prepare_batch(utts)            # host buffers allocated once; every run() is one zv_synthesize_batch
-    call2 = model.prepare_batch(utts)           # second set of output buffers: two batches in flight (lanes 0 and 1)
+    depth = max(1, min(4, int(os.environ.get("ZV_BENCH_LANES", "2"))))       # batches in flight (A/B hook; 2 is what is reported)
+    lanes = [call] + [model.prepare_batch(utts) for _ in range(depth - 1)]   # one set of output buffers per lane
     local_audio_per_step = sum(t * hop / sr for (_, _, _, t) in utts)
 
     def barrier():
@@ -132,21 +133,20 @@ def main():
     # upload, kernels, waveform downloads — before step k - 1 is waited for, so a step's last downloads and copy-out run
     # under the next step's upload and first kernels.  Every step is a whole batch, host ids in -> host waveforms out, and
     # all K steps are complete when the timed region ends.  --no-pipeline: one synchronous zv_synthesize_batch per step.
-    pair = [call, call2]
-
     def run_steps(k_steps):
-        if args.no_pipeline:
+        if args.no_pipeline or depth == 1:
             for _ in range(k_steps):
                 call.run()
             return
         for k in range(k_steps):
-            pair[k & 1].begin(k & 1)
-            if k:
-                pair[(k - 1) & 1].end((k - 1) & 1)
-        if k_steps:
-            pair[(k_steps - 1) & 1].end((k_steps - 1) & 1)
+            lanes[k % depth].begin(k % depth)
+            if k >= depth - 1:
+                j = k - (depth - 1)
+                lanes[j % depth].end(j % depth)
+        for j in range(max(0, k_steps - (depth - 1)), k_steps):
+            lanes[j % depth].end(j % depth)
 
-    run_steps(max(args.warmup, 2))              # both lanes' arenas, staging blocks and graphs exist before the clock starts
+    run_steps(max(args.warmup, depth))          # every lane's arena, staging block and graph exist before the clock starts
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -310,7 +310,7 @@ def main():
                                    "blocks + output conv in 4 utterance groups, each group's waveform download under the next group's kernels), %s" %
                                    (" x %d GPUs = configs[4]" % world if world > 1 else "", len(utts), T,
                                     ("eager launches" if args.no_graph else "hipGraph replay") +
-                                    ("" if args.no_pipeline else "; two batches in flight (step k enqueued before step k - 1 is waited for)")),
+                                    ("" if args.no_pipeline or depth == 1 else "; %d batches in flight (step k enqueued before step k - %d is waited for)" % (depth, depth - 1))),
                        "utterances_per_gpu": len(utts), "utterances_total": n_global, "frames": T,
                        "audio_seconds_per_step": round(local_audio_per_step * world, 3),
                        "phonemes_rank0": int(sum(len(u[0]) for u in utts)),
