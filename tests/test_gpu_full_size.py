@@ -147,6 +147,30 @@ def test_fused_256_channel_stage_vs_reference_golden(ckpt):
     assert np.isfinite(wav).all() and err <= 1e-4
 
 
+@pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T1024_N256.npz"])
+def test_batch_regime_kernels_vs_reference_golden(ckpt, fixture):
+    """the kernels only batches pick by themselves — whole-block kernel with its weights through LDS (two weight buffers),
+    64-channel pair kernel with the LDS weight ring, fused 256-channel stage — forced onto one utterance and checked
+    against the REFERENCE's waveform for that mel, like the default path (not only against our own other regimes)"""
+    from zerovox_cpp_amd import capi, synth
+    path, g, tensors = ckpt("medium")
+    z = np.load(os.path.join(GOLD, fixture))
+    T, s = int(z["T"]), int(z["stride"])
+    mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
+    env = {"ZV_FUSE256": "1", "ZV_TRIPLE_V2": "2", "ZV_PAIR64_RING": "2", "ZV_TRIPLE_CFG": "2512"}
+    os.environ.update(env)
+    try:
+        m = capi.Model(path, 0)
+        wav = m.vocode(mel)
+        m.close()
+    finally:
+        for k in env:
+            del os.environ[k]
+    err = _rms(wav[::s] - z["wav_samples"])
+    print(f"{fixture}: batch-regime kernels, wav rms err (strided vs reference) {err:.3e}")
+    assert np.isfinite(wav).all() and err <= 1e-4
+
+
 def test_vocoder_beyond_max_seq_len_and_regime_change(medium):
     """T is a run-time argument: 2 000 frames (> max_seq_len, and long enough that stage 1 switches to the fused
     kernel by itself).  Samples far from the cut must be the 512-frame run's, bit for bit: the two runs use different
