@@ -716,7 +716,8 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     jobs.tps = (Lmax + BM - 1) / BM;
     dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN * NT - 1) / (WN * NT), njobs);
 #ifdef ZV_STAMPS
-    jobs.stamp = getenv("ZV_STAMP_CONV") && atoi(getenv("ZV_STAMP_CONV")) == (int)grid.y && jobs.j[0].Cin_p >= 1024 && njobs == 1;
+    jobs.stamp = getenv("ZV_STAMP_CONV") && atoi(getenv("ZV_STAMP_CONV")) == (int)grid.y && njobs == 1 &&
+                 (getenv("ZV_STAMP_CIN") ? jobs.j[0].Cin_p == atoi(getenv("ZV_STAMP_CIN")) : jobs.j[0].Cin_p >= 1024);
 #endif
     const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
