@@ -315,16 +315,14 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
 }
 
 // copies the finished waveforms out of the pinned staging block, on a few threads when there is enough to move
-static void scatter_out(const char *pin_wav, const size_t *off, float *const *wav, const uint32_t *T, size_t hop, uint32_t a, uint32_t b,
-                        uint32_t off_base = ~0u)
+// (utterances [a, b) of a launch group; off[], wav[] and T[] are indexed from the group's first utterance)
+static void scatter_out(const char *pin_wav, const size_t *off, float *const *wav, const uint32_t *T, size_t hop, uint32_t a, uint32_t b)
 {
-    if (off_base == ~0u) off_base = a;           // off[] is indexed from the first utterance of the launch group
-    off -= 0;
     size_t total = 0;
     for (uint32_t u = a; u < b; u++) total += (size_t)T[u] * hop * 4;
     const unsigned nth = total > ((size_t)8 << 20) ? 4u : 1u;
     auto work = [&](unsigned k) {
-        for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u - off_base], (size_t)T[u] * hop * 4);
+        for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u], (size_t)T[u] * hop * 4);
     };
     if (nth == 1)
     {
@@ -495,7 +493,7 @@ static void batch_finish(zv_model *m, int lane)
     for (int g = 0; g < pb.G; g++)
     {
         ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
-        scatter_out(pb.h_wav, pb.woff.data(), pb.wav.data(), pb.T.data(), pb.hop, pb.gb[g], pb.gb[g + 1], 0);
+        scatter_out(pb.h_wav, pb.woff.data(), pb.wav.data(), pb.T.data(), pb.hop, pb.gb[g], pb.gb[g + 1]);
     }
     M.sync();                                     // the frame counts (and, unsplit, the waveforms) travel on the lane's stream
     if (pb.n_frames)
