@@ -221,6 +221,7 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"}),
                       ("block_v1", {"ZV_TRIPLE_V2": "0"}), ("block_v2", {"ZV_TRIPLE_V2": "2"}),
                       ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"}),
+                      ("block_v2_512_mt4", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "4512"}),
                       ("pair64_ring", {"ZV_PAIR64_RING": "2"}), ("pair64_ring_no_merge", {"ZV_PAIR64_RING": "2", "ZV_NO_MERGE": "1"}),
                       ("pair64_no_ring", {"ZV_PAIR64_RING": "0"})):
         os.environ.update(env)          # some switches are read when the model is built, some at every launch

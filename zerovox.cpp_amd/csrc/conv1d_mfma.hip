@@ -1785,8 +1785,24 @@ __device__ __forceinline__ void lds_st_b16(unsigned addr, _Float16 h)
     asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(addr), "v"(h), "n"(OFF) : "memory");
 }
 
+// the operand writes of the whole-block kernel, unrolled at compile time (every LDS offset an immediate)
+template <int MT_, int I = 0>
+__device__ __forceinline__ void xwrite_all(unsigned xa, const float (&y)[MT_][16], float sl)
+{
+    constexpr int mt = I / 16, r = I % 16;
+    lds_st_b16<(mt * 32 + (r & 3) + 8 * (r >> 2)) * 80>(xa, (_Float16)lrelu_max(y[mt][r], sl));
+    if constexpr (I + 1 < MT_ * 16) xwrite_all<MT_, I + 1>(xa, y, sl);
+}
+template <int MT_, int I = 0>
+__device__ __forceinline__ void pack_all(unsigned pa, const uint2 (&pk)[MT_][4])
+{
+    constexpr int mt = I / 4, q = I % 4;
+    lds_st_b64<mt * 32 * 80 + 16 * q>(pa, pk[mt][q]);
+    if constexpr (I + 1 < MT_ * 4) pack_all<MT_, I + 1>(pa, pk);
+}
+
 template <int MT, int R>
-__global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel(const TripleJobs jobs)
+__global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32_kernel(const TripleJobs jobs)
 {
     constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
@@ -1878,42 +1894,8 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
         }
         // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
         {
-            static_assert(MT == 2, "the operand writes below are written out for two row tiles per wave");
-            const unsigned xa = (unsigned)(uintptr_t)(smem + (XM + irow0) * RS + col * 2);
-#define ZV_XW(mt, r) lds_st_b16<((mt) * 32 + ((r) & 3) + 8 * ((r) >> 2)) * RS>(xa, (_Float16)lrelu_max(yreg[mt][r], sl));
-            ZV_XW(0, 0)
-            ZV_XW(0, 1)
-            ZV_XW(0, 2)
-            ZV_XW(0, 3)
-            ZV_XW(0, 4)
-            ZV_XW(0, 5)
-            ZV_XW(0, 6)
-            ZV_XW(0, 7)
-            ZV_XW(0, 8)
-            ZV_XW(0, 9)
-            ZV_XW(0, 10)
-            ZV_XW(0, 11)
-            ZV_XW(0, 12)
-            ZV_XW(0, 13)
-            ZV_XW(0, 14)
-            ZV_XW(0, 15)
-            ZV_XW(1, 0)
-            ZV_XW(1, 1)
-            ZV_XW(1, 2)
-            ZV_XW(1, 3)
-            ZV_XW(1, 4)
-            ZV_XW(1, 5)
-            ZV_XW(1, 6)
-            ZV_XW(1, 7)
-            ZV_XW(1, 8)
-            ZV_XW(1, 9)
-            ZV_XW(1, 10)
-            ZV_XW(1, 11)
-            ZV_XW(1, 12)
-            ZV_XW(1, 13)
-            ZV_XW(1, 14)
-            ZV_XW(1, 15)
-#undef ZV_XW
+            static_assert(RS == 80, "xwrite_all / pack_all carry the row stride");
+            xwrite_all<MT>((unsigned)(uintptr_t)(smem + (XM + irow0) * RS + col * 2), yreg, sl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __syncthreads();                       // X complete, conv1's weights landed (the barrier drains the DMA)
@@ -1953,6 +1935,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
         {
             const int hh = lane >> 5;
             const unsigned pa = (unsigned)(uintptr_t)(smem + (XM + wave * 32 * MT + (lane & 31)) * RS + 4 * hh * 2);
+            uint2 pkv[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
             {
@@ -1969,22 +1952,10 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), 4) void resblock_block32_kernel
                         pk.x = in ? pk.x : 0u;
                         pk.y = in ? pk.y : 0u;
                     }
-                    if (mt == 0)
-                    {
-                        if (q == 0) lds_st_b64<0>(pa, pk);
-                        if (q == 1) lds_st_b64<16>(pa, pk);
-                        if (q == 2) lds_st_b64<32>(pa, pk);
-                        if (q == 3) lds_st_b64<48>(pa, pk);
-                    }
-                    else
-                    {
-                        if (q == 0) lds_st_b64<32 * RS>(pa, pk);
-                        if (q == 1) lds_st_b64<32 * RS + 16>(pa, pk);
-                        if (q == 2) lds_st_b64<32 * RS + 32>(pa, pk);
-                        if (q == 3) lds_st_b64<32 * RS + 48>(pa, pk);
-                    }
+                    pkv[mt][q] = pk;
                 }
             }
+            pack_all<MT>(pa, pkv);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __syncthreads();                       // XT complete, conv2's weights landed
@@ -2086,7 +2057,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always (A/B, tests)
     const char *v2_s = getenv("ZV_TRIPLE_V2");           // read per launch: tests switch it between models
     const int v2_env = v2_s ? atoi(v2_s) : 1;
-    if (MT == 2 && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
+    if ((MT == 2 || (MT == 4 && R == 512)) && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
     {
         size_t lds2 = 0;
         const char *db_s = getenv("ZV_TRIPLE_DB");          // read per launch (A/B): 0 = one weight buffer for every branch
@@ -2115,6 +2086,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
                 hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
+            if (MT == 4) return launch(resblock_block32_kernel<4, 512>, 256);
             return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
         }
     }
