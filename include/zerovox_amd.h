@@ -188,6 +188,14 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
 typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLOCK = 2, ZV_LAYER_VAR_PRED = 3 } zv_layer_kind;
 zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out);
 
+/* ---- test / measurement switches (none is needed in production; no reference counterpart: the reference's only run-time
+ * switch is the thread count, src/zerovox.cpp:86-91).  The library reads the environment ONCE, when it is loaded (variables
+ * named like the switches, so that a shell script can A/B a run); afterwards a switch changes only through this call.
+ * Schedule switches (ZV_NO_FUSE, ZV_NO_TRIPLE, ZV_FUSE256, ZV_NO_MERGE, ZV_TAIL_GROUPS, ZV_VOC_GROUP) are sampled when a
+ * model is loaded, kernel-regime switches at every launch.  name == NULL resets every switch to its built-in default.
+ * ZV_ERR_ARG for an unknown name.  The list: zerovox.cpp_amd/csrc/knobs.h. */
+zv_status zv_debug_set(const char *name, int value);
+
 /* ---- GGUF inspection without a device (loader half of the boundary; used by the CPU test-suite) ----
  * Parses the file exactly as zv_model_load does and reports the counts; *max_seq_len receives the
  * `<arch>.max_seq_len` KV.  tensor_index >= 0 additionally returns that tensor's name (<= 63 chars + NUL),

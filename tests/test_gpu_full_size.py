@@ -64,12 +64,10 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
     assert _rms(d) <= 2.0e-3 and np.max(np.abs(d)) <= 1.2e-2
     # two ways to feed the convs their normalised operand (fused prologue for single utterances, one f16 operand pass
     # for batches): same bits, whichever the size picks
-    for v in ("0", "1"):
-        os.environ["ZV_DEC_PREPASS"] = v
-        try:
+    from zerovox_cpp_amd import capi
+    for v in (0, 1):
+        with capi.switches(ZV_DEC_PREPASS=v):
             assert np.array_equal(model.decode(hid, style), mel), v
-        finally:
-            del os.environ["ZV_DEC_PREPASS"]
 
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])
@@ -135,11 +133,8 @@ def test_fused_256_channel_stage_vs_reference_golden(ckpt):
     z = np.load(os.path.join(GOLD, "medium_T512_N64.npz"))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
-    os.environ["ZV_FUSE256"] = "1"
-    try:
+    with capi.switches(ZV_FUSE256=1):      # a schedule switch: sampled when the model is built
         m = capi.Model(path, 0)
-    finally:
-        del os.environ["ZV_FUSE256"]
     wav = m.vocode(mel)
     m.close()
     err = _rms(wav[::s] - z["wav_samples"])
@@ -157,15 +152,10 @@ def test_batch_regime_kernels_vs_reference_golden(ckpt, fixture):
     z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
-    env = {"ZV_FUSE256": "1", "ZV_TRIPLE_V2": "2", "ZV_PAIR64_RING": "2", "ZV_TRIPLE_CFG": "2512"}
-    os.environ.update(env)
-    try:
+    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_TAIL_FUSED=0):
         m = capi.Model(path, 0)
         wav = m.vocode(mel)
         m.close()
-    finally:
-        for k in env:
-            del os.environ[k]
     err = _rms(wav[::s] - z["wav_samples"])
     print(f"{fixture}: batch-regime kernels, wav rms err (strided vs reference) {err:.3e}")
     assert np.isfinite(wav).all() and err <= 1e-4
@@ -224,14 +214,10 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       ("block_v2_512_mt4", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "4512"}),
                       ("pair64_ring", {"ZV_PAIR64_RING": "2"}), ("pair64_ring_no_merge", {"ZV_PAIR64_RING": "2", "ZV_NO_MERGE": "1"}),
                       ("pair64_no_ring", {"ZV_PAIR64_RING": "0"})):
-        os.environ.update(env)          # some switches are read when the model is built, some at every launch
-        try:
+        with capi.switches(**{k: int(v) for k, v in env.items()}):      # some switches are sampled when the model is built, some at every launch
             m = capi.Model(path, 0)
             outs[name] = m.vocode(mel)
             m.close()
-        finally:
-            for k in env:
-                del os.environ[k]
     for name, w in outs.items():
         assert np.array_equal(w, outs["default"]), name
 

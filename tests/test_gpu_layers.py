@@ -89,12 +89,10 @@ def test_every_decoder_residual_block(env, block):
     # distinct frames (InstanceNorm over near-identical frames only measures rounding of the statistics)
     x = (1.2 * np.random.default_rng(300 + block).standard_normal((T, cin))).astype(np.float32)
     style = (0.05 * np.random.default_rng(7).standard_normal(E)).astype(np.float32)
-    for pre in ("0", "1"):                       # both ways of feeding the convs their normalised operand
-        os.environ["ZV_DEC_PREPASS"] = pre
-        try:
+    from zerovox_cpp_amd import capi
+    for pre in (0, 1):                           # both ways of feeding the convs their normalised operand
+        with capi.switches(ZV_DEC_PREPASS=pre):
             got = m.debug_layer(m.LAYER_DEC_BLOCK, block, x, cout, style=style)
-        finally:
-            del os.environ["ZV_DEC_PREPASS"]
         ref, alt = _oracle_pair(o, o.LAYER_DEC_BLOCK, block, x, cout, style=style)
         _check(f"decoder block {block} ({cin}->{cout}) prepass={pre}", got, ref, alt, 3e-4)
 

@@ -261,15 +261,36 @@ def test_batches_in_flight_on_two_lanes_equal_the_synchronous_call(models):
             for (w, nf), (rw, rnf) in zip(res, ref[bi]):
                 assert nf == rnf and np.array_equal(w, rw), (graph, bi)
     c = model.prepare_batch(small)
+    zero_mel = np.zeros((8, g.num_mels), np.float32)
+    ref_v = model.vocode(zero_mel)
     with pytest.raises(capi.ZvError):
         c.end(1)                                   # nothing in flight on that lane
     c.begin(1)
     with pytest.raises(capi.ZvError):
         c.begin(1)                                 # the lane is taken
-    with pytest.raises(capi.ZvError):
-        model.vocode(np.zeros((8, g.num_mels), np.float32))      # a synchronous call would reuse the busy lane's buffers
+    # the synchronous entry points run on lane 0 whatever lane was touched last: lane 1 busy does not stop them ...
+    assert np.array_equal(model.vocode(zero_mel), ref_v)
     c.end(1)
-    assert model.vocode(np.zeros((8, g.num_mels), np.float32)).shape == (8 * g.hop_size,)
+    assert np.array_equal(c.results()[0][0], ref[3][0][0])
+    # ... and lane 0 busy does, also when the lane touched last (1) is idle again: begin(0), begin(1), end(1), then a
+    # synchronous call of every kind must be refused (it would overwrite lane 0's I/O block under its downloads)
+    c0, c1 = model.prepare_batch(batches[0]), model.prepare_batch(small)
+    c0.begin(0)
+    c1.begin(1)
+    c1.end(1)
+    ids, puncts, style = synth.encoder_inputs(g, 5, 12)
+    d = model.device_alloc(8 * g.num_mels * 4 + 8 * g.hop_size * 4)
+    for call in (lambda: model.vocode(zero_mel), lambda: model.synthesize(ids, puncts, style, 64),
+                 lambda: model.encode(ids, puncts, style, 64), lambda: model.decode(np.zeros((8, g.E), np.float32), style),
+                 lambda: model.vocode_stream(zero_mel, 4), lambda: model.vocode_device(d, 8, d + 8 * g.num_mels * 4),
+                 lambda: model.synthesize_batch(small)):
+        with pytest.raises(capi.ZvError):
+            call()
+    c0.end(0)
+    for (w, nf), (rw, rnf) in zip(c0.results(), ref[0]):
+        assert nf == rnf and np.array_equal(w, rw)           # the refused calls left the batch in flight untouched
+    model.device_free(d)
+    assert np.array_equal(model.vocode(zero_mel), ref_v)
     with pytest.raises(capi.ZvError):
         c.begin(capi.BATCH_LANES)                  # no such lane
 

@@ -19,7 +19,7 @@ SYMBOLS = [
     "zv_last_error", "zv_version", "zv_model_load", "zv_model_free", "zv_model_get_hparams", "zv_model_reserve",
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_synthesize_batch_begin", "zv_synthesize_batch_end", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
-    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance", "zv_debug_layer",
+    "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance", "zv_debug_layer", "zv_debug_set",
 ]
 
 
@@ -70,6 +70,7 @@ def load_library(path: Optional[str] = None):
     lib.zv_encode.argtypes = [vp, i32p, i32p, fp, u32, u32, fp, C.POINTER(u32)]
     lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
     lib.zv_debug_layer.argtypes = [vp, C.c_int, C.c_int, fp, u32, fp, fp]
+    lib.zv_debug_set.argtypes = [C.c_char_p, C.c_int]
     lib.zv_max_frames.argtypes = [vp]
     lib.zv_max_frames.restype = u32
     lib.zv_demo_utterance.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
@@ -107,6 +108,31 @@ def load_library(path: Optional[str] = None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def debug_set(name: Optional[str], value: int = 0):
+    """zv_debug_set: one test / measurement switch (csrc/knobs.h); name None resets every switch to its default"""
+    lib = load_library()
+    st = lib.zv_debug_set(None if name is None else name.encode(), int(value))
+    if st != 0:
+        raise ZvError(st, lib.zv_last_error().decode())
+
+
+class switches:
+    """`with capi.switches(ZV_NO_FUSE=1, ...):` — the switches hold inside the block (schedule switches are sampled by
+    Model(), kernel-regime switches at every launch) and every switch is back at its default afterwards"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            debug_set(k, int(v))
+        return self
+
+    def __exit__(self, *exc):
+        debug_set(None)
+        return False
 
 
 class Model:

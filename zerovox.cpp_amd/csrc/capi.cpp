@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "model.h"
+#include "knobs.h"
 
 using zv::Model;
 
@@ -19,7 +20,7 @@ struct zv_model
 };
 
 static void free_pending(zv_model *m);
-static void need_idle(zv_model *m);      // fails when the lane the next call would run on has a batch in flight
+static void use_lane0(zv_model *m);      // selects lane 0 (the lane of every synchronous entry point); fails when lane 0 has a batch in flight
 
 static thread_local std::string g_last_error;
 
@@ -134,9 +135,8 @@ zv_status zv_encode_taps(zv_model *m, const int32_t *ids, const int32_t *puncts,
         ZV_NEED(n > 0, "n must be > 0");
         ZV_NEED(num_phonemes <= n, "num_phonemes exceeds n");
         Model &M = *m->m;
-        need_idle(m);
+        use_lane0(m);
         check_T(M, T);
-        ZV_HIP(hipSetDevice(M.device));
         check_ids(M, ids, puncts, n);
         const size_t E = M.E();
         const size_t b_ids = (size_t)n * 4, b_sty = E * 4, b_hid = (size_t)T * E * 4;
@@ -176,9 +176,8 @@ zv_status zv_decode(zv_model *m, const float *hidden, const float *style, uint32
     return guarded([&] {
         ZV_NEED(m && hidden && style && mel, "null argument");
         Model &M = *m->m;
-        need_idle(m);
+        use_lane0(m);
         check_T(M, T);
-        ZV_HIP(hipSetDevice(M.device));
         const size_t E = M.E(), Mm = M.hp.audio_num_mels;
         const size_t b_hid = (size_t)T * E * 4, b_sty = (E * 4 + 255) & ~(size_t)255, b_mel = (size_t)T * Mm * 4;
         char *io = (char *)M.io_scratch(b_hid + b_sty + b_mel + 1024);
@@ -196,9 +195,8 @@ zv_status zv_vocode(zv_model *m, const float *mel, uint32_t T, float *wav)
     return guarded([&] {
         ZV_NEED(m && mel && wav, "null argument");
         Model &M = *m->m;
-        need_idle(m);
+        use_lane0(m);
         check_T(M, T);
-        ZV_HIP(hipSetDevice(M.device));
         const size_t b_mel = ((size_t)T * M.hp.audio_num_mels * 4 + 255) & ~(size_t)255, b_wav = (size_t)T * M.hp.audio_hop_size * 4;
         char *io = (char *)M.io_scratch(b_mel + b_wav);
         float *d_mel = (float *)io, *d_wav = (float *)(io + b_mel);
@@ -217,9 +215,7 @@ zv_status zv_vocode_stream(zv_model *m, const float *mel, uint32_t T, uint32_t c
         ZV_NEED(m && mel && sink, "null argument");
         ZV_NEED(T > 0 && chunk_frames > 0, "T and chunk_frames must be > 0");
         Model &M = *m->m;
-        need_idle(m);
-        ZV_HIP(hipSetDevice(M.device));
-        M.select_lane(0);
+        use_lane0(m);
         const size_t Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
         const uint32_t H = M.vocoder_halo_frames();
         const uint32_t ctx_max = std::min<uint64_t>(T, (uint64_t)chunk_frames + 2 * H);
@@ -304,9 +300,7 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
         ZV_NEED(m && ids && puncts && style && wav, "null argument");
         ZV_NEED(n > 0 && T > 0, "n and T must be > 0");
         Model &M = *m->m;
-        need_idle(m);
-        ZV_HIP(hipSetDevice(M.device));
-        M.select_lane(0);
+        use_lane0(m);
         int32_t nf = 0;
         synthesize_enqueue(M, ids, puncts, style, n, T, wav, &nf);
         M.sync();
@@ -364,11 +358,14 @@ static void free_pending(zv_model *m)
     delete[] m->pending;
     m->pending = nullptr;
 }
-static void need_idle(zv_model *m)
+static void use_lane0(zv_model *m)
 {
-    const int l = m->m->current_lane();
-    if (m->pending && l < ZV_BATCH_LANES && m->pending[l].active)
-        zv::fail(ZV_ERR_ARG, "lane %d has a batch in flight (zv_synthesize_batch_begin): finish it with zv_synthesize_batch_end first", l);
+    // the synchronous and device-resident entry points run on lane 0's stream, arena and I/O block whatever lane was
+    // touched last: select it FIRST, then refuse the call while a batch of that lane is still reading those buffers
+    if (m->pending && m->pending[0].active)
+        zv::fail(ZV_ERR_ARG, "lane 0 has a batch in flight (zv_synthesize_batch_begin): finish it with zv_synthesize_batch_end first");
+    if (hipSetDevice(m->m->device) != hipSuccess) zv::fail(ZV_ERR_DEVICE, "hipSetDevice(%d) failed", m->m->device);
+    m->m->select_lane(0);
 }
 
 static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *const *ids, const int32_t *const *puncts,
@@ -390,6 +387,7 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
     zv::Batch bt;
     bt.nseg = (int)n_utt;
     bt.n_max = zv::round_up((int)nmax, 32);
+    bt.n_real = (int)nmax;
     bt.t_max = zv::round_up((int)tmax, 64);
     bt.n_rows = (size_t)bt.nseg * bt.n_max;
     bt.t_rows = (size_t)bt.nseg * bt.t_max;
@@ -441,36 +439,47 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
     // run.  Same kernels on the same rows: same bits.
     const int G = (M.tail_groups() > 1 && bt.nseg >= 2 * M.tail_groups() && wav_bytes >= ((size_t)16 << 20) && !M.profiling && M.dbg_layer.kind < 0)
                       ? M.tail_groups() : 1;
-    hipStream_t cs = M.copy_stream();
-    pb.gb.assign(G + 1, n_utt);
-    pb.gb[0] = 0;
-    if (G <= 1)
+    // from here on work is queued that reads the lane's pinned input block and writes its I/O block: if anything fails the
+    // lane's streams are drained before the error leaves, so an idle-looking lane never has work in flight
+    try
     {
-        M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
-        ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
-        ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
-        ZV_HIP(hipEventRecord(M.tail_event(1), M.stream));
+        hipStream_t cs = M.copy_stream();
+        pb.gb.assign(G + 1, n_utt);
+        pb.gb[0] = 0;
+        if (G <= 1)
+        {
+            M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
+            ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+            ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
+            ZV_HIP(hipEventRecord(M.tail_event(1), M.stream));
+        }
+        else
+        {
+            M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
+            ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
+            for (int g = 1; g < G; g++)               // contiguous groups of about wav_bytes / G each
+            {
+                uint32_t u = pb.gb[g - 1] + 1;
+                while (u < n_utt && pb.woff[u] < wav_bytes * g / G) u++;
+                pb.gb[g] = std::min(u, n_utt - (uint32_t)(G - g));
+            }
+            for (int g = 0; g < G; g++)
+            {
+                const uint32_t u0 = pb.gb[g], u1 = pb.gb[g + 1];
+                M.vocode_tail(bt, d_mel, d_wav, (int)u0, (int)(u1 - u0));
+                const size_t o0 = pb.woff[u0], o1 = u1 < n_utt ? pb.woff[u1] : wav_bytes;
+                ZV_HIP(hipEventRecord(M.tail_event(2 * g), M.stream));
+                ZV_HIP(hipStreamWaitEvent(cs, M.tail_event(2 * g), 0));
+                ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
+                ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
+            }
+        }
     }
-    else
+    catch (...)
     {
-        M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
-        ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
-        for (int g = 1; g < G; g++)               // contiguous groups of about wav_bytes / G each
-        {
-            uint32_t u = pb.gb[g - 1] + 1;
-            while (u < n_utt && pb.woff[u] < wav_bytes * g / G) u++;
-            pb.gb[g] = std::min(u, n_utt - (uint32_t)(G - g));
-        }
-        for (int g = 0; g < G; g++)
-        {
-            const uint32_t u0 = pb.gb[g], u1 = pb.gb[g + 1];
-            M.vocode_tail(bt, d_mel, d_wav, (int)u0, (int)(u1 - u0));
-            const size_t o0 = pb.woff[u0], o1 = u1 < n_utt ? pb.woff[u1] : wav_bytes;
-            ZV_HIP(hipEventRecord(M.tail_event(2 * g), M.stream));
-            ZV_HIP(hipStreamWaitEvent(cs, M.tail_event(2 * g), 0));
-            ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
-            ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
-        }
+        hipStreamSynchronize(M.stream);
+        if (M.copy_stream()) hipStreamSynchronize(M.copy_stream());
+        throw;
     }
     pb.active = true;
     pb.n_utt = n_utt;
@@ -489,13 +498,24 @@ static void batch_finish(zv_model *m, int lane)
     PendingBatch &pb = pending_slot(m, lane);
     if (!pb.active) zv::fail(ZV_ERR_ARG, "lane %d has no batch in flight", lane);
     M.select_lane(lane);
-    pb.active = false;
-    for (int g = 0; g < pb.G; g++)
+    try
     {
-        ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
-        scatter_out(pb.h_wav, pb.woff.data(), pb.wav.data(), pb.T.data(), pb.hop, pb.gb[g], pb.gb[g + 1]);
+        for (int g = 0; g < pb.G; g++)
+        {
+            ZV_HIP(hipEventSynchronize(M.tail_event(2 * g + 1)));
+            scatter_out(pb.h_wav, pb.woff.data(), pb.wav.data(), pb.T.data(), pb.hop, pb.gb[g], pb.gb[g + 1]);
+        }
+        M.sync();                                 // the frame counts (and, unsplit, the waveforms) travel on the lane's stream
     }
-    M.sync();                                     // the frame counts (and, unsplit, the waveforms) travel on the lane's stream
+    catch (...)
+    {
+        // a failed wait: drain what can be drained, then give the lane up as idle (its buffers are no longer in use)
+        hipStreamSynchronize(M.stream);
+        if (M.copy_stream()) hipStreamSynchronize(M.copy_stream());
+        pb.active = false;
+        throw;
+    }
+    pb.active = false;
     if (pb.n_frames)
         for (uint32_t u = 0; u < pb.n_utt; u++) pb.n_frames[u] = (uint32_t)pb.h_nf[u];
 }
@@ -508,6 +528,8 @@ static void batch_check(Model &M, uint32_t n_utt, const int32_t *const *ids, con
         ZV_NEED(ids[u] && puncts[u] && styles[u] && wav[u], "null utterance pointer");
         ZV_NEED(n_phonemes[u] > 0 && T[u] > 0, "n and T must be > 0");
         check_T(M, T[u]);
+        if (n_phonemes[u] > M.max_phonemes())
+            zv::fail(ZV_ERR_ARG, "utterance %u: %u phonemes exceed the %u rows of the sinusoid table", u, n_phonemes[u], M.max_phonemes());
         check_ids(M, ids[u], puncts[u], n_phonemes[u]);
     }
 }
@@ -583,9 +605,7 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
         ZV_NEED(m && x && out, "null argument");
         ZV_NEED(rows > 0, "rows must be > 0");
         Model &M = *m->m;
-        need_idle(m);
-        ZV_HIP(hipSetDevice(M.device));
-        M.select_lane(0);
+        use_lane0(m);
         ZV_NEED(!M.graph_mode, "zv_debug_layer runs eagerly: turn graph mode off");
         const size_t E = M.E(), Mm = M.hp.audio_num_mels, hop = M.hp.audio_hop_size;
         std::vector<float> zsty(E, 0.f);
@@ -638,6 +658,18 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
     });
 }
 
+zv_status zv_debug_set(const char *name, int value)
+{
+    return guarded([&] {
+        if (!name)
+        {
+            zv::knob_reset();
+            return;
+        }
+        if (!zv::knob_set(name, value)) zv::fail(ZV_ERR_ARG, "unknown switch '%s'", name);
+    });
+}
+
 // ---- device-resident entry points ---------------------------------------------------------------
 
 void *zv_device_alloc(zv_model *m, size_t bytes)
@@ -686,7 +718,7 @@ zv_status zv_vocode_device(zv_model *m, const float *d_mel, uint32_t T, float *d
     return guarded([&] {
         ZV_NEED(m && d_mel && d_wav, "null argument");
         check_T(*m->m, T);
-        ZV_HIP(hipSetDevice(m->m->device));
+        use_lane0(m);
         m->m->vocode_dev_graph(zv::Batch::single(1, T, 1), d_mel, d_wav);
     });
 }
@@ -696,7 +728,7 @@ zv_status zv_decode_device(zv_model *m, const float *d_hidden, const float *d_st
     return guarded([&] {
         ZV_NEED(m && d_hidden && d_style && d_mel, "null argument");
         check_T(*m->m, T);
-        ZV_HIP(hipSetDevice(m->m->device));
+        use_lane0(m);
         m->m->decode_dev(zv::Batch::single(1, T, 1), d_hidden, d_style, d_mel);
     });
 }

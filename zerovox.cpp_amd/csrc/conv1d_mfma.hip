@@ -19,6 +19,7 @@
 // Several independent convs that share a tile configuration (the three MRF branches of a HiFi-GAN
 // stage) ride in one launch as "jobs" (blockIdx.z) so that a 512-frame utterance still fills 256 CUs.
 #include "kernels.h"
+#include "knobs.h"
 
 #include <hip/hip_fp16.h>
 #include <algorithm>
@@ -722,8 +723,8 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     jobs.tps = (Lmax + BM - 1) / BM;
     dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN * NT - 1) / (WN * NT), njobs);
 #ifdef ZV_STAMPS
-    jobs.stamp = getenv("ZV_STAMP_CONV") && atoi(getenv("ZV_STAMP_CONV")) == (int)grid.y && njobs == 1 &&
-                 (getenv("ZV_STAMP_CIN") ? jobs.j[0].Cin_p == atoi(getenv("ZV_STAMP_CIN")) : jobs.j[0].Cin_p >= 1024);
+    jobs.stamp = knob(ZV_STAMP_CONV) && knob(ZV_STAMP_CONV) == (int)grid.y && njobs == 1 &&
+                 (knob(ZV_STAMP_CIN) ? jobs.j[0].Cin_p == knob(ZV_STAMP_CIN) : jobs.j[0].Cin_p >= 1024);
 #endif
     const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -740,7 +741,7 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
     if (njobs < 1 || njobs > CONV_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
-    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
+    const int dbg = knob(ZV_DBG);
     ConvJobs js;
     js.segs = segs;
     js.rate = rate;
@@ -779,29 +780,16 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
         const double ai = 2.0 * jobs[0].K * jobs[0].Cin_p * Cout_p / (4.0 * (jobs[0].Cin_p + Cout_p));
         if (ai < 200.0 && wgs(1, 1) >= 16L * n_cu) MT = std::min(MT, Cout_p <= 128 ? 2 : 1);
     }
-    {   // measurement hook (environment table): ZV_CONV_MT=<minimum MT>
-        static const char *e_mt = getenv("ZV_CONV_MT");
-        if (e_mt && MT < atoi(e_mt)) MT = atoi(e_mt);
-        // ZV_CONV_MTMAX=<mt>[,<max K*Cin_p>]: cap the tile height (for convs whose contraction is at most that long)
-        static const char *e_mx = getenv("ZV_CONV_MTMAX");
-        if (e_mx)
-        {
-            const int cap = atoi(e_mx);
-            const char *c = strchr(e_mx, ',');
-            const int kmax = c ? atoi(c + 1) : (1 << 30);
-            if (jobs[0].K * jobs[0].Cin_p <= kmax && MT > cap) MT = cap;
-        }
-    }
+    if (MT < knob(ZV_CONV_MT)) MT = knob(ZV_CONV_MT);      // measurement hook: minimum MT
     // two output tiles per wave once a conv is wide and the launch still has rounds of workgroups to spare
-    static const int nt_env = getenv("ZV_CONV_NT") ? atoi(getenv("ZV_CONV_NT")) : 0;
+    const int nt_env = knob(ZV_CONV_NT);
     int NT = (WN == 4 && ntiles >= 8 && MT >= 2 && wgs(MT, 2) >= 4L * n_cu) ? 2 : 1;
     if (nt_env == 1 || (nt_env == 2 && WN == 4 && ntiles >= 2 && MT >= 2)) NT = nt_env;
     if (NT == 2 && MT == 4) MT = 2;        // 64 x 64 per wave: the 128 x 64 shape does not fit 256 registers
     {
         // single-utterance launches (at most a round of workgroups, one wave per SIMD): the deep-lookahead loop for the
         // 256-channel chunks
-        const char *de = getenv("ZV_CONV_SINGLE");         // read per launch (A/B, tests)
-        if ((de ? atoi(de) != 0 : true) && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= 2L * n_cu)
+        if (knob(ZV_CONV_SINGLE) != 0 && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= 2L * n_cu)
         {
             if (WN == 4) return launch_cfg<1, 4, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
             if (WN == 2) return launch_cfg<1, 2, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
@@ -1479,15 +1467,14 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
-    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
-    static const int mt_env = getenv("ZV_PAIR_MT") ? atoi(getenv("ZV_PAIR_MT")) : 0;
+    const int dbg = knob(ZV_DBG), mt_env = knob(ZV_PAIR_MT);
     PairJobs js;
     js.segs = segs;
     js.rate = rate;
     js.njobs = njobs;
     js.merge_out = merge_out;
 #ifdef ZV_STAMPS
-    js.stamp = getenv("ZV_STAMP_CP") && atoi(getenv("ZV_STAMP_CP")) == jobs[0].Cp && !merge_out;
+    js.stamp = knob(ZV_STAMP_CP) && knob(ZV_STAMP_CP) == jobs[0].Cp && !merge_out;
 #endif
     const int Lmax = segs.max_rows * rate;
     int Kmax = 0, dmax = 0;
@@ -1516,8 +1503,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // the 64-channel stage does not care (-1 %).  The tile height never changes an output bit.
     // 64 channels, batches: the form with the weights through an LDS ring (ZV_PAIR64_RING = 0 never, 2 whenever it fits)
     {
-        const char *ring_s = getenv("ZV_PAIR64_RING");      // read per launch: tests switch it between models
-        const int ring_env = ring_s ? atoi(ring_s) : 1;
+        const int ring_env = knob(ZV_PAIR64_RING);
         bool ok = Cp == 64 && ring_env != 0 && Kmax >= 3 && (256 + Kmax * dmax) * 144 + 4 * 8192 + 1024 <= 80 * 1024;
         for (int i = 0; i < njobs && ok; i++) ok = jobs[i].w1r && jobs[i].w2r;
         const long rwgs = (long)((Lmax + 256 - Kmax) / (257 - Kmax)) * segs.nseg * njobs;
@@ -2020,16 +2006,15 @@ bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
-    static const int dbg = getenv("ZV_DBG") ? atoi(getenv("ZV_DBG")) : 0;
-    const char *cfg_s = getenv("ZV_TRIPLE_CFG");
-    const int cfg_env = cfg_s ? atoi(cfg_s) : 0;      // A/B hook: MT*1000 + R
+    const int dbg = knob(ZV_DBG);
+    const int cfg_env = knob(ZV_TRIPLE_CFG);          // A/B hook: MT*1000 + R
     TripleJobs js;
     js.segs = segs;
     js.rate = rate;
     js.interleave = 1;
     js.db_mask = 0;
 #ifdef ZV_STAMPS
-    js.stamp = getenv("ZV_STAMP_CP") && atoi(getenv("ZV_STAMP_CP")) == 32;
+    js.stamp = knob(ZV_STAMP_CP) == 32;
 #endif
     // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are enough rows
     // for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
@@ -2055,12 +2040,10 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(round_up(gx, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
     // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always (A/B, tests)
-    const char *v2_s = getenv("ZV_TRIPLE_V2");           // read per launch: tests switch it between models
-    const int v2_env = v2_s ? atoi(v2_s) : 1;
+    const int v2_env = knob(ZV_TRIPLE_V2);
     if ((MT == 2 || (MT == 4 && R == 512)) && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
     {
         size_t lds2 = 0;
-        const char *db_s = getenv("ZV_TRIPLE_DB");          // read per launch (A/B): 0 = one weight buffer for every branch
         js.db_mask = 0;
         for (int i = 0; i < njobs; i++)
         {
@@ -2071,14 +2054,13 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
             const int nb = ((P.K * 2 + 3) >> 2) >> 1;
             // operand tile + weight buffer(s) + 2 fragments (the last B prefetch) + the block's biases
             const size_t one = (size_t)round_up((int)(rows * 80), 1024) + (size_t)(8 * nb + 2) * 1024 + 1024;
-            const bool db = (db_s ? atoi(db_s) != 0 : true) && one + (size_t)8 * nb * 1024 <= 80 * 1024;
+            const bool db = knob(ZV_TRIPLE_DB) != 0 && one + (size_t)8 * nb * 1024 <= 80 * 1024;
             if (db) js.db_mask |= 1 << i;
             lds2 = std::max(lds2, one + (db ? (size_t)8 * nb * 1024 : 0));
         }
         if (lds2 <= 80 * 1024)
         {
-            const char *il_s = getenv("ZV_TRIPLE_INTERLEAVE");
-            js.interleave = (il_s ? atoi(il_s) != 0 : true) ? njobs : 1;
+            js.interleave = knob(ZV_TRIPLE_INTERLEAVE) != 0 ? njobs : 1;
             const dim3 grid2 = js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid;
             auto launch = [&](auto kern, int nth) {
                 hipError_t e = lds2 > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) : hipSuccess;

@@ -3,6 +3,7 @@
 // Every kernel maps a workgroup to (segment, tile inside the segment) — see `Segs` in kernels.h — so one launch
 // covers all utterances of a batch while each utterance keeps its own extents.
 #include "kernels.h"
+#include "knobs.h"
 
 namespace zv
 {
@@ -637,8 +638,7 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
     const int n = segs.max_rows;
     const int KSTR = dk | 1;
     const size_t lds_mfma = ((size_t)64 * KSTR + 1 + (size_t)((n + 31) & ~31) * 64) * sizeof(float);
-    static const bool force_scalar = getenv("ZV_ATT_SCALAR") && atoi(getenv("ZV_ATT_SCALAR")) != 0;     // test hook
-    static const bool force_mfma = getenv("ZV_ATT_MFMA") && atoi(getenv("ZV_ATT_MFMA")) != 0;               // test hook
+    const bool force_scalar = knob(ZV_ATT_SCALAR) != 0, force_mfma = knob(ZV_ATT_MFMA) != 0;     // test hooks
     const long wgs_mfma = (long)((n + 63) / 64) * H * segs.nseg;
     if (!force_scalar && (dk & 3) == 0 && dk <= 2 * ATT_NS_MAX && (ld & 3) == 0 && lds_mfma <= (size_t)ATT_LDS_MAX &&
         (wgs_mfma >= 48 || force_mfma))

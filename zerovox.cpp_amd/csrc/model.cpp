@@ -1,5 +1,6 @@
 // model.cpp — loader + fixed kernel schedules (see model.h).
 #include "model.h"
+#include "knobs.h"
 
 #include <algorithm>
 #include <cmath>
@@ -142,12 +143,13 @@ Model::Model(const std::string &path, int dev) : device(dev)
     ZV_HIP(hipGetDeviceProperties(&prop, dev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) fail(ZV_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
     n_cu = prop.multiProcessorCount;
-    no_fuse_ = getenv("ZV_NO_FUSE") && atoi(getenv("ZV_NO_FUSE")) != 0;
-    no_triple_ = getenv("ZV_NO_TRIPLE") && atoi(getenv("ZV_NO_TRIPLE")) != 0;
-    force_fuse256_ = getenv("ZV_FUSE256") && atoi(getenv("ZV_FUSE256")) != 0;
-    no_merge_ = getenv("ZV_NO_MERGE") && atoi(getenv("ZV_NO_MERGE")) != 0;
-    voc_group_ = getenv("ZV_VOC_GROUP") ? atoi(getenv("ZV_VOC_GROUP")) : 0;
-    tail_groups_ = getenv("ZV_TAIL_GROUPS") ? atoi(getenv("ZV_TAIL_GROUPS")) : 4;
+    // schedule switches are fixed when the model is built (knobs.h: tests force a regime, measurements A/B one)
+    no_fuse_ = knob(ZV_NO_FUSE) != 0;
+    no_triple_ = knob(ZV_NO_TRIPLE) != 0;
+    force_fuse256_ = knob(ZV_FUSE256) != 0;
+    no_merge_ = knob(ZV_NO_MERGE) != 0;
+    voc_group_ = knob(ZV_VOC_GROUP);
+    tail_groups_ = knob(ZV_TAIL_GROUPS);
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
     lanes_[0].stream = stream;
@@ -630,7 +632,9 @@ void Model::arena_require(size_t bytes)
 {
     if (bytes <= arena_.cap) return;
     ZV_HIP(hipStreamSynchronize(stream));
-    if (cur_lane_ == 0) drop_graphs();
+    // captured graphs hold pointers into the arena they were captured on: whichever lane regrows its arena, every graph
+    // goes (growth happens a handful of times per process, outside timed regions)
+    drop_graphs();
     if (arena_.base) hipFree(arena_.base);
     arena_ = DeviceArena();
     void *p = nullptr;
@@ -638,7 +642,7 @@ void Model::arena_require(size_t bytes)
     // on the lane's own stream: the streams are non-blocking, so a memset on the null stream is NOT ordered with the
     // kernels that follow on `stream` and could zero an arena they have already started to fill
     // ZV_ARENA_FILL=255 fills it with NaN patterns instead: no kernel may depend on what a fresh arena holds (test hook)
-    static const int fill = getenv("ZV_ARENA_FILL") ? atoi(getenv("ZV_ARENA_FILL")) : 0;
+    const int fill = knob(ZV_ARENA_FILL);
     ZV_HIP(hipMemsetAsync(p, fill, bytes, stream));
     arena_.base = (char *)p;
     arena_.cap = bytes;
@@ -1157,7 +1161,7 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     // pass writes the f16 operand (launch_norm_act_f16) and the conv copies it (PRO_RAW_F16) — right when launches have
     // many rounds of workgroups: a 1 056-wide conv stages every input tile 9 times (once per group of 128 output
     // channels), so (a) repeats the f32 prologue 9 times and reads twice the bytes.
-    const int pre_env = getenv("ZV_DEC_PREPASS") ? atoi(getenv("ZV_DEC_PREPASS")) : -1;      // test / A-B hook, read per call
+    const int pre_env = knob(ZV_DEC_PREPASS);      // test / A-B hook
     const bool prepass = pre_env >= 0 ? pre_env != 0 : (size_t)bt.t_max * bt.nseg >= 4096;
 
     // D2: all ten AdaIN fc layers at once for every utterance's style vector            (src/stylettsdec.cpp:175-189)
@@ -1323,7 +1327,9 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
                                      float *d_hidden, int32_t *d_nframes)
 {
     if (bt.n_rows == 0 || bt.t_rows == 0 || bt.n_max <= 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "N and T must be > 0");
-    if (bt.n_max > enc_.posenc_rows) fail(ZV_ERR_ARG, "%d phonemes exceed the %d rows of the sinusoid table", bt.n_max, enc_.posenc_rows);
+    // the real extents decide (the kernels walk each segment's own rows); n_max is a capacity rounded up for grid sizing
+    const int n_longest = bt.n_real > 0 ? bt.n_real : bt.n_max;
+    if (n_longest > enc_.posenc_rows) fail(ZV_ERR_ARG, "%d phonemes exceed the %d rows of the sinusoid table", n_longest, enc_.posenc_rows);
     arena_require(arena_bytes_for(bt.n_rows, bt.t_rows, bt.nseg));
     arena_.used = 0;
     const Segs tk = bt.tokens(), fr = bt.frames();

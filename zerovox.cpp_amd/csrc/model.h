@@ -55,6 +55,7 @@ struct Batch
 {
     int        nseg = 1;
     int        n_max = 0, t_max = 0;        // >= every utterance's phonemes / frames
+    int        n_real = 0;                  // the longest utterance's real phoneme count (checks; not part of a graph's key)
     size_t     n_rows = 0, t_rows = 0;      // >= sum of phonemes / frames (rows of the concatenated buffers)
     const Seg *d_tok = nullptr, *d_frm = nullptr;
     Seg        tok1{0, 0, 0, 0}, frm1{0, 0, 0, 0};
@@ -63,6 +64,7 @@ struct Batch
     {
         Batch b;
         b.n_max = (int)N;
+        b.n_real = (int)N;
         b.t_max = (int)T;
         b.n_rows = N;
         b.t_rows = T;
@@ -132,6 +134,8 @@ class Model
         bool         done = false;
     } dbg_layer;
 
+    // rows of the sinusoid table = the longest utterance the encoder takes (reference src/fs2encoder.cpp:306-324)
+    uint32_t max_phonemes() const { return (uint32_t)enc_.posenc_rows; }
     void reserve(uint32_t max_phonemes, uint32_t max_frames);
     void reserve_batch(const Batch &b);
     int  voc_stage_rate(int stage) const;       // samples per frame after upsample stage `stage`
