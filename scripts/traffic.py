@@ -3,9 +3,19 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads, + WRITE_SIZE), weighted over the
 family's launches, with the launch durations of the kernel trace of the same build.
 usage: traffic.py <pmc.txt> <kernel_trace_summary.txt> <tag>"""
-import json, re, sys
+import hashlib, json, os, re, sys
 pmc, trace, tag = sys.argv[1:4]
-fam = ("resblock_pair_kernel", "resblock_pair64_kernel", "resblock_triple_kernel", "resblock_block32_kernel")
+fam = ("resblock_pair_kernel", "resblock_pair64_kernel", "resblock_triple_kernel", "resblock_block32_kernel", "resblock_tail_kernel",
+       "resblock_block64_kernel")
+SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zerovox.cpp_amd", "csrc", "conv1d_mfma.hip")
+
+
+def stage_of(key):
+    """vocoder stage (s0 .. s3 = 256 / 128 / 64 / 32 channels) of a kernel configuration"""
+    if key.startswith("resblock_pair_kernel<256"): return "s0"
+    if key.startswith("resblock_pair_kernel<128"): return "s1"
+    if key.startswith(("resblock_pair64_kernel", "resblock_pair_kernel<64", "resblock_block64_kernel")): return "s2"
+    return "s3"
 fetch, write, n = {}, {}, {}
 sect = None
 for ln in open(pmc):
@@ -41,7 +51,15 @@ for k in fetch:
     tot_b += b * n[k]
     tot_n += n[k]
     tot_us += us * n[k]
-out = {"kernel_rev": tag, "workload": "bench.py batch: 32 utterances x 1024 frames per launch",
+passes = min(n.values()) if n else 1          # a configuration that runs once per pass exists in every stage's schedule
+per_stage = {}
+for k in per:
+    st = per_stage.setdefault(stage_of(k), {"hbm_bytes_per_pass": 0.0, "launches_per_pass": 0.0, "us_per_pass": 0.0})
+    st["hbm_bytes_per_pass"] += per[k]["hbm_bytes_per_launch"] * n[k] / passes
+    st["launches_per_pass"] += n[k] / passes
+    st["us_per_pass"] += (per[k]["avg_launch_us"] or 0.0) * n[k] / passes
+out = {"kernel_rev": tag, "kernel_src_sha256": hashlib.sha256(open(SRC, "rb").read()).hexdigest(),
+       "kernel_src": "zerovox.cpp_amd/csrc/conv1d_mfma.hip", "passes": passes, "per_stage": per_stage, "workload": "bench.py batch: 32 utterances x 1024 frames per launch",
        "hbm_bytes_per_launch": tot_b / tot_n if tot_n else None, "avg_launch_us": tot_us / tot_n if tot_n else None,
        "method": "per kernel configuration: 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, separate --pmc passes; "
                  "averaged over the family's dispatches; durations from the kernel trace of the same build",

@@ -103,6 +103,102 @@ def numph_case(tmp="/tmp"):
     os.remove(path)
 
 
+def robust_case(tmp="/tmp", search=0):
+    """An UN-FORCED end-to-end golden: ZeroVOXModel::eval's chain (src/zerovox.cpp:326-334) on an utterance whose integer
+    decisions do not depend on summation order.  Geometry medium8 (8 variance bins); the utterance seed was found by
+    search (search=N re-runs it over N seeds with our oracle, which reproduces the reference bit for bit): every pitch /
+    energy prediction >= 0.1 bin from a bucket boundary, every duration >= 0.04 frames from a rounding boundary.  Besides
+    the reference's outputs the fixture stores the reference semantics' own un-forced re-association noise (our oracle in
+    sequential-f32 order against the reference): the floor the GPU is gated against."""
+    g = synth.GEOMETRIES["medium8"]
+    path = os.path.join(tmp, "golden_medium8.gguf")
+    synth.write_checkpoint(path, g, SEED_W)
+    _, tensors = gguf.read_gguf(path)
+    N, T, seed = 16, 96, 11167
+    nb = g.ve_n_bins
+
+    def margins(e):
+        def bm(p):
+            x = p.astype(np.float64) * (nb - 1) + 0.5
+            fr = x - np.floor(x)
+            m = np.minimum(fr, 1 - fr)
+            m = np.where(x < 0, -x, m)
+            return np.where(x >= nb, x - nb + 1, m)
+        d = np.exp(e["logdur"].astype(np.float64)) - 1.0 + 0.5
+        fd = d - np.floor(d)
+        return float(bm(e["pitch"]).min()), float(bm(e["energy"]).min()), float(np.where(d < 0, -d, np.minimum(fd, 1 - fd)).min())
+
+    orc = zvoracle.Oracle(tensors, threads=8)
+    if search:
+        best = (0.0, seed)
+        for sd in range(1000, 1000 + search):
+            ids, puncts, style = synth.encoder_inputs(g, sd, N)
+            mp, me, md = margins(orc.encoder(g, ids, puncts, style, T))
+            best = max(best, (min(mp, me, 4 * md), sd))
+        seed = best[1]
+    ids, puncts, style = synth.encoder_inputs(g, seed, N)
+    r = zvoracle.run_reference_chain(path, ids, puncts, style, T=T)
+    e = orc.encoder(g, ids, puncts, style, T)        # (the reference's pitch tap is recycled by its graph allocator: ours)
+    assert np.array_equal(e["hidden"], r["hidden"]) and e["n_frames"] == r["n_frames"]
+    mp, me, md = margins(e)
+    alt = zvoracle.Oracle(tensors, threads=8, order=zvoracle.ORDER_SEQ_F32)
+    ea = alt.encoder(g, ids, puncts, style, T)
+    mela = alt.decoder(ea["hidden"], style)
+    wava = alt.vocoder(mela)
+    assert ea["n_frames"] == r["n_frames"] and np.array_equal(ea["pitch_bucket"], r["pitch_bucket"]) and np.array_equal(ea["energy_bucket"], r["energy_bucket"])
+    rms = lambda a: float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+    out = dict(geometry="medium8", seed_w=SEED_W, T=T, N=N, seed_enc=seed, n_frames=r["n_frames"], logdur=r["logdur"],
+               pitch=e["pitch"], energy=r["energy"], pitch_bucket=r["pitch_bucket"], energy_bucket=r["energy_bucket"],
+               margin_pitch_bins=mp, margin_energy_bins=me, margin_duration_frames=md,
+               hidden_sha256=sha(r["hidden"]), mel=r["mel"], wav=r["wav"], wav_rms=rms(r["wav"]), mel_rms=rms(r["mel"]),
+               floor_wav_rms=rms(wava - r["wav"]), floor_wav_max=float(np.max(np.abs(wava - r["wav"]))),
+               floor_mel_rms=rms(mela - r["mel"]), floor_mel_max=float(np.max(np.abs(mela - r["mel"]))),
+               floor_hidden_max=float(np.max(np.abs(ea["hidden"] - r["hidden"]))))
+    np.savez_compressed(os.path.join(HERE, "robust_medium8_T%d_N%d.npz" % (T, N)), **out)
+    print("robust un-forced case: seed %d frames %d margins pitch %.3f energy %.3f bins, duration %.3f frames; un-forced floor wav rms %.3e mel max %.3e"
+          % (seed, r["n_frames"], mp, me, md, out["floor_wav_rms"], out["floor_mel_max"]))
+    os.remove(path)
+
+
+def add_floors(tmp="/tmp"):
+    """the reference semantics' own re-association noise on each full-size fixture's stage inputs (our oracle in sequential-f32
+    order against the stored reference samples): the floor the GPU's stage outputs are gated against (1.5 x), stored in
+    the fixture itself so that the tests carry no hand-written tolerance"""
+    g = synth.MEDIUM
+    path = os.path.join(tmp, "golden_medium.gguf")
+    synth.write_checkpoint(path, g, SEED_W)
+    _, tensors = gguf.read_gguf(path)
+    alt = zvoracle.Oracle(tensors, threads=8, order=zvoracle.ORDER_SEQ_F32)
+    rms = lambda a: float(np.sqrt(np.mean(np.asarray(a, np.float64) ** 2)))
+    for name in ("medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"):
+        f = os.path.join(HERE, name)
+        z = dict(np.load(f))
+        T, s_ = int(z["T"]), int(z["stride"])
+        mel_in = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
+        hid_in = synth.decoder_hidden(g, int(z["seed_hidden"]), T)
+        _, _, style = synth.encoder_inputs(g, int(z["seed_enc"]), int(z["N"]))
+        dm = alt.decoder(hid_in, style).reshape(-1)[::s_] - z["mel_samples"]
+        dw = alt.vocoder(mel_in)[::s_] - z["wav_samples"]
+        z.update(floor_mel_max=float(np.max(np.abs(dm))), floor_mel_rms=rms(dm), floor_wav_rms=rms(dw), floor_wav_max=float(np.max(np.abs(dw))))
+        np.savez_compressed(f, **z)
+        print(name, "floors: mel max %.3e rms %.3e, wav rms %.3e" % (z["floor_mel_max"], z["floor_mel_rms"], z["floor_wav_rms"]))
+    # the reference's demo utterance (chain mode: the decoder's input is the reference's own hidden, not regenerable from a
+    # seed): teacher-force our oracle with the reference's hidden / mel via the reference chain's outputs
+    from zerovox_cpp_amd import capi
+    f = os.path.join(HERE, "demo_medium_T1500.npz")
+    z = dict(np.load(f))
+    ids, puncts, style = capi.demo_utterance()
+    T, s_ = int(z["T"]), int(z["stride"])
+    r = zvoracle.run_reference_chain(path, ids, puncts, style, T=T)
+    dm = alt.decoder(r["hidden"], style).reshape(-1)[::s_] - z["mel_samples"]
+    dw = alt.vocoder(r["mel"])[::s_] - z["wav_samples"]
+    z.update(floor_mel_max=float(np.max(np.abs(dm))), floor_mel_rms=rms(dm), floor_wav_rms=rms(dw), floor_wav_max=float(np.max(np.abs(dw))))
+    np.savez_compressed(f, **z)
+    print("demo floors (stages teacher-forced with the reference's own hidden / mel): mel max %.3e rms %.3e, wav rms %.3e"
+          % (z["floor_mel_max"], z["floor_mel_rms"], z["floor_wav_rms"]))
+    os.remove(path)
+
+
 def norm_kat():
     src = "/root/reference/utils/norm1dexample.json"
     if not os.path.exists(src):
@@ -127,3 +223,5 @@ if __name__ == "__main__":
     norm_kat()
     demo_case()
     numph_case()
+    robust_case()
+    add_floors()

@@ -38,8 +38,9 @@ def test_config2_vocoder_512_frames_vs_reference_golden(medium, fixture):
     wav = model.vocode(mel)
     assert wav.shape == (T * 300,) and np.isfinite(wav).all()
     err = _rms(wav[::s] - z["wav_samples"])
-    print(f"config2: wav rms err (strided vs reference) {err:.3e}; reference wav rms {float(z['wav_rms']):.3f}")
-    assert err <= 1e-4
+    print(f"config2: wav rms err (strided vs reference) {err:.3e}; reference wav rms {float(z['wav_rms']):.3f}; "
+          f"re-association floor of this fixture {float(z['floor_wav_rms']):.3e}")
+    assert err <= 1e-4 and err <= 1.5 * float(z["floor_wav_rms"])
     # determinism + graph replay gives the same bits as eager launches
     model.set_graph_mode(True)
     w2 = model.vocode(mel)
@@ -61,13 +62,23 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
     print(f"decoder T={T}: mel err max {np.max(np.abs(d)):.3e} rms {_rms(d):.3e} (mel rms {float(z['mel_rms']):.3f}; "
           f"reference self-noise floor at this size: max ~3e-3..4e-3, rms ~1e-3 — SURVEY.md Appx D)")
     assert np.isfinite(mel).all()
-    assert _rms(d) <= 2.0e-3 and np.max(np.abs(d)) <= 1.2e-2
+    # gate: 1.5 x the reference semantics' own re-association noise on THIS input, measured when the fixture was made
+    # (tests/golden/make_golden.py add_floors) — north_star's absolute 1e-3 max-abs gate is below that floor on these weights
+    fl_max, fl_rms = float(z["floor_mel_max"]), float(z["floor_mel_rms"])
+    print(f"   floor of this fixture: max {fl_max:.3e} rms {fl_rms:.3e} -> ratios {np.max(np.abs(d)) / fl_max:.2f} / {_rms(d) / fl_rms:.2f}")
+    assert _rms(d) <= 1.5 * fl_rms and np.max(np.abs(d)) <= 1.5 * fl_max
     # two ways to feed the convs their normalised operand (fused prologue for single utterances, one f16 operand pass
     # for batches): same bits, whichever the size picks
     from zerovox_cpp_amd import capi
     for v in (0, 1):
         with capi.switches(ZV_DEC_PREPASS=v):
             assert np.array_equal(model.decode(hid, style), mel), v
+        # the batch form of the wide convs (loader waves + double-buffered tile) forced onto one utterance, and the
+        # single-utterance MFMA loop switched off: same chain per output element, same bits
+        with capi.switches(ZV_DEC_PREPASS=v, ZV_CONV_LW=2):
+            assert np.array_equal(model.decode(hid, style), mel), ("loader waves", v)
+        with capi.switches(ZV_DEC_PREPASS=v, ZV_CONV_SINGLE=0):
+            assert np.array_equal(model.decode(hid, style), mel), ("no single loop", v)
 
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])
@@ -152,7 +163,7 @@ def test_batch_regime_kernels_vs_reference_golden(ckpt, fixture):
     z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
-    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_TAIL_FUSED=0):
+    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_MERGE_ALWAYS=1, ZV_CONV_LW=2):
         m = capi.Model(path, 0)
         wav = m.vocode(mel)
         m.close()
@@ -209,6 +220,10 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
     outs = {}
     for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"}),
                       ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"}),
+                      ("merge", {"ZV_MERGE_ALWAYS": "1"}), ("fuse256_merge", {"ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1"}),
+                      ("pair64_ring_merge", {"ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1"}),
+                      ("single_loop_everywhere", {"ZV_CONV_SINGLE": "2"}), ("no_single_loop", {"ZV_CONV_SINGLE": "0"}),
+                      ("loader_waves", {"ZV_CONV_LW": "2"}),
                       ("block_v1", {"ZV_TRIPLE_V2": "0"}), ("block_v2", {"ZV_TRIPLE_V2": "2"}),
                       ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"}),
                       ("block_v2_512_mt4", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "4512"}),

@@ -110,8 +110,10 @@ def test_demo_utterance_stage_by_stage_vs_reference(models):
     dw = wav[::s] - z["wav_samples"]
     print(f"demo utterance: frames {e['n_frames']} (reference {int(z['n_frames'])}), bucket flips {flips}, mel err max "
           f"{np.max(np.abs(dm)):.3e} rms {_rms(dm):.3e}, wav rms err {_rms(dw):.3e} (wav rms {float(z['wav_rms']):.3f})")
-    assert _rms(dm) <= 2.0e-3 and np.max(np.abs(dm)) <= 1.5e-2
-    assert _rms(dw) <= 1e-4
+    # gates: 1.5 x the re-association floor stored in the fixture (our oracle in sequential-f32 order against the reference
+    # on the same teacher-forced stage inputs), and the absolute wav gate
+    assert _rms(dm) <= 1.5 * float(z["floor_mel_rms"]) and np.max(np.abs(dm)) <= 1.5 * float(z["floor_mel_max"])
+    assert _rms(dw) <= 1e-4 and _rms(dw) <= 1.5 * float(z["floor_wav_rms"])
     # the chained call is the three stage calls back to back
     w2, nf2 = model.synthesize(ids, puncts, style, T)
     assert nf2 == e["n_frames"] and np.array_equal(w2, model.vocode(model.decode(e["hidden"], style)))

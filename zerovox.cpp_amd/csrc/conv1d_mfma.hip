@@ -43,6 +43,10 @@ static constexpr int CK_MAX = 256;
 #ifndef ZV_STAGE_U
 #define ZV_STAGE_U 4
 #endif
+// waves per SIMD the 64 x 64 wave-tile instantiation of the generic conv kernel is compiled for (3: 168 registers)
+#ifndef ZV_NT2_OCC
+#define ZV_NT2_OCC 3
+#endif
 
 int conv_pick_ck(int Cin_p, int ck_max)
 {
@@ -220,6 +224,49 @@ __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *sme
     }
 }
 
+// PRO_RAW_F16 in 16-byte pieces (8 channels) for NTH threads: every load of a round is in flight before the first is
+// stored (U x 16 B per thread), so a tile of <= NTH * U pieces costs one round trip.  Used by the loader waves.
+template <int U, int NTH>
+__device__ __forceinline__ void stage_raw16(const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid)
+{
+    const int cols = ck >> 3;
+    const int total = rows * cols;
+    const int L = J.L;
+    int r = tid / cols, c8 = tid - r * cols;
+    const int dr = NTH / cols, dc = NTH - dr * cols;
+    for (int base = tid; base < total; base += NTH * U)
+    {
+        uint4 v[U];
+        int lofs[U];
+        bool live[U], inr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            live[u] = base + u * NTH < total;
+            const int t = row_t0 + r;
+            inr[u] = live[u] && t >= 0 && t < L;
+            lofs[u] = r * RS + c8 * 16;
+            v[u] = *(const uint4 *)((const _Float16 *)J.x0 + (size_t)(inr[u] ? t : 0) * J.ldx + c0 + c8 * 8);
+            r += dr;
+            c8 += dc;
+            if (c8 >= cols) { c8 -= cols; r++; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (live[u]) *(uint4 *)(smem + lofs[u]) = inr[u] ? v[u] : make_uint4(0, 0, 0, 0);
+    }
+}
+
+// a tile staged by NTH of the workgroup's threads (tid = 0 .. NTH-1)
+template <int U, int NTH>
+__device__ __forceinline__ void stage_any(int pro, const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid)
+{
+    if (pro == PRO_RAW_F16 && (ck & 7) == 0)
+        stage_raw16<(U > 8 ? U : 8), NTH>(J, smem, RS, c0, ck, row_t0, rows, tid);
+    else
+        stage_tile<(U > 4 ? 4 : U), NTH>(pro, J, smem, RS, c0, ck, row_t0, rows, tid);
+}
+
 // ---- compute: S = K * nkc MFMA steps over one staged chunk.  A fragments are double-buffered in registers
 // (the ds_reads of step s+1 are in flight while the MFMAs of step s run), B fragments come from L2 through a
 // 4-deep register ring.
@@ -357,6 +404,46 @@ __device__ __forceinline__ void mfma_taps(floatx16 (&acc)[MT][NT], const char *a
 #undef ZV_A_ADDR
 }
 
+
+// mfma_taps with ONE set of four weight-fragment slots: the slot a step has consumed is refilled at once with the fragment
+// of four steps later (same prefetch distance as the two ping-pong sets above, half their registers: the 64 x 64 wave tile
+// then fits 168 registers = three workgroups per CU instead of two).  Same step order, same bits.
+template <int CP, int MT, int NT>
+__device__ __forceinline__ void mfma_taps_ring4(floatx16 (&acc)[MT][NT], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K)
+{
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    static_assert(NKC >= 8, "whole 8-step bodies per tap");
+    constexpr bool HALF = NKC == 16;
+    const int nb = (K * NKC) >> 3;
+    half8 b[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b[u][nt] = wq[nt * wseg + u * 64];
+    half8 a0[MT], a1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) a0[mt] = *(const half8 *)(ap + mt * 32 * RS);
+#define ZV_R4_LOADA(dst, un)                                                                  \
+    {                                                                                         \
+        const char *np_ = (un) == 8 ? apn : ap + (un) * 32;                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) dst[mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+    }
+#define ZV_R4_STEP(u, acur, anext)                                                            \
+    ZV_R4_LOADA(anext, (u) + 1)                                                               \
+    mfma_step<MT, NT, false>(acc, acur, b[(u) & 3]);                                          \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[(u) & 3][nt] = wq[nt * wseg + ((u) + 4) * 64]; \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ib = 0; ib < nb; ib++)
+    {
+        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + dilRS;   // next body
+        ZV_R4_STEP(0, a0, a1) ZV_R4_STEP(1, a1, a0) ZV_R4_STEP(2, a0, a1) ZV_R4_STEP(3, a1, a0)
+        ZV_R4_STEP(4, a0, a1) ZV_R4_STEP(5, a1, a0) ZV_R4_STEP(6, a0, a1) ZV_R4_STEP(7, a1, a0)
+        ap = apn;
+        wq += 8 * 64;
+    }
+#undef ZV_R4_STEP
+#undef ZV_R4_LOADA
+}
 
 // The same loop with the A fragments TWO steps ahead (four register sets in rotation) and a scheduling fence after
 // every step.  In the loop above hipcc moves each A read down next to the MFMA that consumes it (an lgkmcnt wait right
@@ -549,8 +636,13 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 // (Measured dead end, round 2: the staged tile double-buffered in LDS and filled by LDS-DMA while the MFMA loop of the
 // previous chunk runs.  hipcc answers an LDS-DMA in flight with vmcnt(0) waits on the B-fragment stream of the MFMA
 // loop — the counted waits that keep eight fragments in flight are gone — and the wide decoder convs ran 3 % slower.)
-template <int MT, int WN, int NT, bool SINGLE = false>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs)
+// LW > 0 (multi-chunk convs of a batch: the wide decoder / encoder convs): LW extra "loader" waves stage chunk c + 1 into
+// the other half of a double-buffered LDS tile while the four compute waves run the MFMA loop of chunk c — one barrier per
+// chunk, the compute waves issue no vector-memory instruction besides their weight-fragment stream (whose counted waits
+// therefore survive), and the staging round trip that phase stamps showed as 5.5-6.2 us in front of every 6.4-7.7 us
+// MFMA loop (profiles/r02_v2_stamps_decoder_conv.txt) disappears behind it.  Same chain per output element: same bits.
+template <int MT, int WN, int NT, bool SINGLE = false, int LW = 0>
+__global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC == 3)) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
@@ -569,13 +661,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const bool is_loader = LW > 0 && wave >= 4;
+    const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
 
     const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
     const int nicb = Cin_p >> 4;
     const int ntiles = (Cout_p + 31) >> 5;
     const int nt0 = (blockIdx.y * WN + wn) * NT;
-    const bool n_ok = nt0 < ntiles;
+    const bool n_ok = nt0 < ntiles && !is_loader;
     // a wave whose second tile does not exist computes the last tile twice and stores it once
     const int ntl = nt0 + NT <= ntiles ? nt0 : (ntiles - NT > 0 ? ntiles - NT : 0);
     const int rows = BM + (K - 1) * dil;
@@ -616,11 +709,65 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
     int stamp_k = 1;
 #endif
     ZV_STAMP(0)
+    if constexpr (LW > 0)
+    {
+        // tile buffers 0 / 1 alternate per chunk; chunk 0 is staged by every thread of the workgroup
+        const int tile_bytes = round_up((rows + dil) * RS, 16);
+        const int nchunk = (Cin_p + J.ck - 1) / J.ck;
+        if (!(J.dbg & 1))
+        {
+            const int ck0 = Cin_p < J.ck ? Cin_p : J.ck;
+            stage_any<8, 256 + 64 * LW>(J.pro, S, smem, RS, 0, ck0, m0 - J.pad, rows, tid);
+        }
+        __syncthreads();
+        for (int ic = 0; ic < nchunk; ic++)
+        {
+            const int c0 = ic * J.ck;
+            const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
+            char *cur = smem + (ic & 1) * tile_bytes;
+            if (is_loader)
+            {
+                if (ic + 1 < nchunk && !(J.dbg & 1))
+                {
+                    const int c1 = c0 + J.ck;
+                    const int ck1 = (Cin_p - c1 < J.ck) ? (Cin_p - c1) : J.ck;
+                    stage_any<16, 64 * LW>(J.pro, S, smem + ((ic + 1) & 1) * tile_bytes, RS, c1, ck1, m0 - J.pad, rows, tid - 256);
+                }
+            }
+            else if (n_ok && !(J.dbg & 2))
+            {
+                const char *ab = abase + (ic & 1) * tile_bytes;
+                const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
+                const size_t wseg = (size_t)K * nicb * 64;
+                if (ck == 256 && J.ck == 256)
+                    mfma_taps<256, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
+                else if (ck == 128 && J.ck == 128)
+                    mfma_taps<128, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
+                else if (ck == 64 && J.ck == 64)
+                    mfma_taps<64, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
+                else
+                    mfma_chunk<MT, NT>(acc, ab, RS, dil, wp, wseg, K, ck >> 4);
+            }
+            (void)cur;
+            // the next chunk's tile is complete and this chunk's tile is free again
+            if (ic + 1 < nchunk) __syncthreads();
+        }
+        if (is_loader) return;
+    }
+    else
     for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
-        if (!(J.dbg & 1)) stage_tile<ZV_STAGE_U>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        if (!(J.dbg & 1))
+        {
+            // an f16 operand tensor (the decoder's pre-pass output) in 16-byte pieces, a 64-row x 256-channel tile in ONE round
+            // trip (9 pieces per thread in flight); the 8-byte pieces of stage_tile took four (phase stamps: 5.5-6.2 us per chunk)
+            if (J.pro == PRO_RAW_F16 && (ck & 7) == 0 && !SINGLE)
+                stage_raw16<(BM >= 64 ? 9 : 5), 256>(S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+            else
+                stage_tile<ZV_STAGE_U>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+        }
         __syncthreads();
 #ifdef ZV_STAMPS
         if (stamp_k < 10) { ZV_STAMP(stamp_k) stamp_k++; }
@@ -635,6 +782,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
             {
                 if (ck == 256 && single256)
                     mfma_taps_single256<MT>(acc, abase, dil * RS, wp, K, bring);
+                else
+                    mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
+            }
+            else if constexpr (NT == 2)
+            {
+                // the 64 x 64 wave tile keeps to loops with ONE set of four weight-fragment slots (168 registers: three
+                // workgroups per CU)
+                if (ck == 256 && J.ck == 256)
+                    mfma_taps_ring4<256, MT, NT>(acc, abase, dil * RS, wp, wseg, K);
                 else
                     mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
             }
@@ -667,26 +823,30 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
         const int oc = nt * 32 + (lane & 31);
         if (oc >= Cout_p) continue;
         const float bias = J.bias ? J.bias[oc] : 0.f;
+        // every residual load of the output tile column in flight before the first use (one round trip per 32 output
+        // channels, not one per 32 x 32 tile: the weight-fragment registers of the MFMA loop are free by now)
+        float resv[MT][16];
+        if (has_res)
+        {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    resv[mt][r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
         {
-            float resv[16];
-            if (has_res)
-            {
-#pragma unroll
-                for (int r = 0; r < 16; r++)          // all 16 residual loads in flight before the first use
-                {
-                    const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                    resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
-                }
-            }
             float outv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++)
             {
                 const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[mt][n][r] + bias;
-                if (has_res) v = v + resv[r];
+                if (has_res) v = v + resv[mt][r];
                 v = v * escale;
                 if (J.eact) v = lrelu(v, J.oslope);
                 outv[r] = v;
@@ -714,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvJobs jobs
 #endif
 }
 
-template <int MT, int WN, int NT, bool SINGLE = false>
+template <int MT, int WN, int NT, bool SINGLE = false, int LW = 0>
 static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int halo, int ck, int dmax_)
 {
     constexpr int WM = 4 / WN;
@@ -726,15 +886,16 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     jobs.stamp = knob(ZV_STAMP_CONV) && knob(ZV_STAMP_CONV) == (int)grid.y && njobs == 1 &&
                  (knob(ZV_STAMP_CIN) ? jobs.j[0].Cin_p == knob(ZV_STAMP_CIN) : jobs.j[0].Cin_p >= 1024);
 #endif
-    const size_t lds = (size_t)(BM + halo + dmax_) * (ck * 2 + 16);   // + dil rows: mfma_taps prefetches one tap past the end
+    // + dil rows: mfma_taps prefetches one tap past the end; LW: two tile buffers
+    const size_t lds = (size_t)round_up((BM + halo + dmax_) * (ck * 2 + 16), 16) * (LW > 0 ? 2 : 1);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE>;
+    auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE, LW>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, jobs);
+    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * LW), lds, s, jobs);
     return hipGetLastError();
 }
 
@@ -789,10 +950,29 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
     {
         // single-utterance launches (at most a round of workgroups, one wave per SIMD): the deep-lookahead loop for the
         // 256-channel chunks
-        if (knob(ZV_CONV_SINGLE) != 0 && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= 2L * n_cu)
+        // ... of convs with SEVERAL such chunks (the decoder's): measured per launch at 512 frames, the one-chunk 256-channel
+        // convs of HiFi-GAN stage 1 take 23.0 us on this loop against 20.0 us on mfma_taps (profiles/r02_v2_single_utterance_kernel_trace.txt
+        // vs round 1's trace), the five-chunk decoder convs 29.6 against 33
+        if (knob(ZV_CONV_SINGLE) != 0 && MT == 1 && NT == 1 && ck == 256 && wgs(1, 1) <= 2L * n_cu &&
+            (jobs[0].Cin_p > 256 || knob(ZV_CONV_SINGLE) == 2))
         {
             if (WN == 4) return launch_cfg<1, 4, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
             if (WN == 2) return launch_cfg<1, 2, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
+        }
+    }
+    {
+        // batches, convs of several input-channel chunks (the wide decoder / encoder convs): loader waves + two tile buffers
+        // (ZV_CONV_LW = 0 never, 2 whenever the shape allows)
+        const int lw_env = knob(ZV_CONV_LW);
+        bool multi = true;
+        for (int i = 0; i < njobs; i++) multi = multi && jobs[i].Cin_p > jobs[i].ck;
+        const size_t tile2 = 2 * (size_t)round_up((32 * (MT >= 2 ? 2 : 1) * (4 / WN) + halo + dmax) * (ck * 2 + 16), 16);
+        if (lw_env && multi && WN == 4 && tile2 <= 80 * 1024 && (lw_env == 2 || wgs(MT, NT) >= 4L * n_cu))
+        {
+            // 64 x 32 per compute wave (147 registers: three waves per SIMD = two 6-wave workgroups per CU; the 64 x 64 and
+            // 128 x 32 wave tiles need 200+ registers and would leave the CU to one workgroup)
+            if (MT >= 2) return launch_cfg<2, 4, 1, false, 2>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
+            return launch_cfg<1, 4, 1, false, 2>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
         }
     }
 #define ZV_CASE(mt, wn, nt) \

@@ -15,6 +15,7 @@ enum Knob : int
     ZV_NO_TRIPLE,          // 1: never the whole-block kernels
     ZV_FUSE256,            // 1: fused pair kernel for the 256-channel stage at any length
     ZV_NO_MERGE,           // 1: three branch outputs instead of their sum
+    ZV_MERGE_ALWAYS,       // 1: the merged MRF sum at any length (default: only with rounds of workgroups to spare)
     ZV_VOC_GROUP,          // G > 0: the vocoder runs G utterances at a time (experiment)
     ZV_TAIL_GROUPS,        // utterance groups of a batch's last vocoder stage (default 4)
     ZV_ARENA_FILL,         // byte a fresh activation arena is filled with (255: NaN patterns)
@@ -22,7 +23,8 @@ enum Knob : int
     ZV_DBG,                // timing-only ablation bits (wrong results)
     ZV_CONV_MT,            // minimum tile height of the generic conv kernel
     ZV_CONV_NT,            // 1 / 2: output tiles per wave of the generic conv kernel
-    ZV_CONV_SINGLE,        // 0: never the single-utterance MFMA loop
+    ZV_CONV_SINGLE,        // 0: never the single-utterance MFMA loop, 2: also for one-chunk convs
+    ZV_CONV_LW,            // 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs
     ZV_PAIR_MT,            // 2 / 4: tile height of the pair kernels
     ZV_PAIR64_RING,        // 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring
     ZV_TRIPLE_CFG,         // MT * 1000 + R of the whole-block kernel

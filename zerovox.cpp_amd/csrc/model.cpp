@@ -996,7 +996,12 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             }
             // the last pair of the stage: the three branches' outputs are only ever used summed (MRF, :300-315), so the
             // workgroups run all three branches of a tile and store the sum alone
-            const bool merge = fused && !no_merge_ && !dbg_here && d == voc_.n_dil - 1;
+            // ... once the merged launch (a third of the workgroups, each three times as long) still has rounds of workgroups to
+            // spare: at one round (a single 512-frame utterance) the merged 128- / 64-channel launches took 45.7 / 37.3 us against
+            // 28.4 / 32.8 us for the three branches side by side, more than the upsample conv gains from reading one tensor
+            const int merge_tile = Cp >= 256 ? 54 : (Cp == 128 ? 118 : 246);
+            const bool merge_pays = knob(ZV_MERGE_ALWAYS) != 0 || Lbatch / merge_tile >= 4L * n_cu;
+            const bool merge = fused && !no_merge_ && !dbg_here && d == voc_.n_dil - 1 && merge_pays;
             if (merge)
             {
                 float *ms = (pj[0].out != pj[0].y && pj[0].out != pj[1].y && pj[0].out != pj[2].y) ? pj[0].out : nullptr;
@@ -1012,7 +1017,10 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 conv(j2, 3, fr, rate, "voc_resblock_conv", b2, f2);
             }
         }
-        group_end("voc_resblock_conv");
+        // one profile entry per stage (bench.py prices every stage against its own binding roof)
+        static const char *const rb_names[8] = {"voc_resblock_s0", "voc_resblock_s1", "voc_resblock_s2", "voc_resblock_s3",
+                                                "voc_resblock_s4", "voc_resblock_s5", "voc_resblock_s6", "voc_resblock_s7"};
+        group_end(rb_names[i < 8 ? i : 7]);
         if (dbg_here)
         {
             dbg_extract(ycur[dbg_layer.index % voc_.n_rb], Cp, Cout, L);
