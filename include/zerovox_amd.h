@@ -184,8 +184,19 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
  *   ZV_LAYER_ENC_FFT       index l: FFTBlock l = attention sublayer + conv FFN (src/fs2encoder.cpp:71-140,174-228)
  *   ZV_LAYER_DEC_BLOCK     index 0,1: ResBlk1d encode.{0,1}; 2..6: AdainResBlk1d decode.{0..4} with `style`
  *                          (src/stylettsdec.cpp:69-149,242-304); cin as the reference (decode.0..2 take the 2E+64 concat)
- *   ZV_LAYER_VAR_PRED      index 0 duration / 1 pitch / 2 energy: VariancePredictor (src/fs2encoder.cpp:386-440), out [rows] */
-typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLOCK = 2, ZV_LAYER_VAR_PRED = 3 } zv_layer_kind;
+ *   ZV_LAYER_VAR_PRED      index 0 duration / 1 pitch / 2 energy: VariancePredictor (src/fs2encoder.cpp:386-440), out [rows]
+ *   ZV_LAYER_VOC_UPSAMPLE  index i: leaky_relu(0.1) + conv_transpose1d i (src/hifigan.cpp:22-71,281-297); x [rows][Cin] at the
+ *                          stage's INPUT rate (rows a multiple of it), out [rows * scale_i][Cout]
+ *   ZV_LAYER_VOC_INPUT     mel normalisation + input conv k7 (src/hifigan.cpp:242-265): x [T][num_mels] -> out [T][channels]
+ *   ZV_LAYER_VOC_OUTPUT    leaky_relu(0.01) + output conv k7 + tanh (src/hifigan.cpp:324-345): x [T * hop][C_last] (the MRF mean)
+ *                          -> out [T * hop]
+ *   ZV_LAYER_DEC_ASR_RES   asr_res: conv 1x1 + InstanceNorm (src/stylettsdec.cpp:382-396): x [T][E] -> out [T][64]
+ *   ZV_LAYER_DEC_TO_OUT    to_out: conv 1x1 + bias (src/stylettsdec.cpp:432-441): x [T][E] -> out [T][num_mels]
+ *   ZV_LAYER_ENC_EMBED     word + punctuation embedding + positional encoding (src/fs2encoder.cpp:306-324): x [N][2] = (phoneme id,
+ *                          punctuation id) as floats -> out [N][E] */
+typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLOCK = 2, ZV_LAYER_VAR_PRED = 3,
+               ZV_LAYER_VOC_UPSAMPLE = 4, ZV_LAYER_VOC_INPUT = 5, ZV_LAYER_VOC_OUTPUT = 6, ZV_LAYER_DEC_ASR_RES = 7,
+               ZV_LAYER_DEC_TO_OUT = 8, ZV_LAYER_ENC_EMBED = 9 } zv_layer_kind;
 zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out);
 
 /* ---- test / measurement switches (none is needed in production; no reference counterpart: the reference's only run-time

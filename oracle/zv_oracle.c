@@ -970,6 +970,95 @@ int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int col
         if (index < 0 || index > 2) return fail("predictor %d", index);
         rc = variance_predictor(c, x, rows, cols, pf[index], ksz[0], out);
     }
+    else if (kind == ZVO_LAYER_VOC_UPSAMPLE)           /* x = leaky_relu(x, 0.1); conv_transpose1d(index): src/hifigan.cpp:281-297, 22-71 */
+    {
+        static const int scales[4] = {5, 5, 4, 3};     /* src/zerovox.cpp:129 */
+        if (index < 0 || index > 3) return fail("upsample %d", index);
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *up = NULL;
+        int OC = 0, OL = 0;
+        transpose(x, rows, cols, xc);
+        lrelu_inplace(xc, (size_t)rows * cols, 0.1f);
+        rc = conv_transpose_cf(c, xc, rows, cols, index, scales[index], &up, &OC, &OL);
+        if (!rc && OL != rows * scales[index]) rc = fail("upsample %d: %d rows out of %d", index, OL, rows);
+        if (!rc) transpose(up, OC, OL, out);
+        free(xc); free(up);
+    }
+    else if (kind == ZVO_LAYER_VOC_INPUT)              /* src/hifigan.cpp:242-265 */
+    {
+        const zvo_tensor *mean = get(c, "hifigan.mean"), *scale = get(c, "hifigan.scale");
+        const zvo_tensor *iw = get(c, "_meldec.input_conv.w"), *ib = get(c, "_meldec.input_conv.b");
+        if (!mean || !scale || !iw || !ib) return -1;
+        if (cols != (int)mean->ne[0]) return fail("input conv wants %d mel channels", (int)mean->ne[0]);
+        const float *mu = (const float *)mean->data, *sc = (const float *)scale->data;
+        const int C0 = (int)iw->ne[2], K = (int)iw->ne[0];
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *yc = (float *)malloc((size_t)rows * C0 * 4);
+        for (int t = 0; t < rows; t++)
+            for (int m = 0; m < cols; m++) xc[(size_t)m * rows + t] = (x[(size_t)t * cols + m] - mu[m]) / sc[m];
+        rc = conv_named(c, xc, rows, cols, iw, ib, (K - 1) / 2, 1, yc, NULL);
+        if (!rc) transpose(yc, C0, rows, out);
+        free(xc); free(yc);
+    }
+    else if (kind == ZVO_LAYER_VOC_OUTPUT)             /* src/hifigan.cpp:324-345 */
+    {
+        const zvo_tensor *ow = get(c, "_meldec.output_conv.1.w"), *ob = get(c, "_meldec.output_conv.1.b");
+        if (!ow || !ob) return -1;
+        const int K = (int)ow->ne[0];
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *o = (float *)malloc((size_t)rows * 4);
+        transpose(x, rows, cols, xc);
+        lrelu_inplace(xc, (size_t)rows * cols, (float)1e-2);
+        rc = conv_named(c, xc, rows, cols, ow, ob, (K - 1) / 2, 1, o, NULL);
+        if (!rc)
+            for (int t = 0; t < rows; t++) out[t] = tanhf(o[t]);
+        free(xc); free(o);
+    }
+    else if (kind == ZVO_LAYER_DEC_ASR_RES)            /* src/stylettsdec.cpp:382-396 */
+    {
+        const zvo_tensor *a0w = get(c, "_mel_decoder.asr_res.0.w"), *a0b = get(c, "_mel_decoder.asr_res.0.b");
+        const zvo_tensor *a1w = get(c, "_mel_decoder.asr_res.1.w"), *a1b = get(c, "_mel_decoder.asr_res.1.b");
+        if (!a0w || !a0b || !a1w || !a1b) return -1;
+        const int R = (int)a0w->ne[2];
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *t0 = (float *)malloc((size_t)rows * R * 4), *t1 = (float *)malloc((size_t)rows * R * 4);
+        transpose(x, rows, cols, xc);
+        rc = conv_named(c, xc, rows, cols, a0w, a0b, 0, 1, t0, NULL);
+        if (!rc)
+        {
+            instnorm_affine_cf(t0, R, rows, (const float *)a1w->data, (const float *)a1b->data, t1);
+            transpose(t1, R, rows, out);
+        }
+        free(xc); free(t0); free(t1);
+    }
+    else if (kind == ZVO_LAYER_DEC_TO_OUT)             /* src/stylettsdec.cpp:432-441 */
+    {
+        const zvo_tensor *tow = get(c, "_mel_decoder.to_out.0.w"), *tob = get(c, "_mel_decoder.to_out.0.b");
+        if (!tow || !tob) return -1;
+        const int M = (int)tow->ne[2];
+        float *xc = (float *)malloc((size_t)rows * cols * 4), *o = (float *)malloc((size_t)rows * M * 4);
+        transpose(x, rows, cols, xc);
+        rc = conv_named(c, xc, rows, cols, tow, NULL, 0, 1, o, NULL);
+        const float *b = (const float *)tob->data;                /* bias added on the [80,T] frame-major view */
+        if (!rc)
+            for (int t = 0; t < rows; t++)
+                for (int m = 0; m < M; m++) out[(size_t)t * M + m] = o[(size_t)m * rows + t] + b[m];
+        free(xc); free(o);
+    }
+    else if (kind == ZVO_LAYER_ENC_EMBED)              /* src/fs2encoder.cpp:306-324; x[n] = (id, punct) as floats */
+    {
+        const zvo_tensor *we = get(c, "_pe._enc.src_word_emb.w"), *pe = get(c, "_pe._enc.punct_embed.w");
+        const zvo_tensor *st = get(c, "sinusoid_encoding_table");
+        if (!we || !pe || !st) return -1;
+        if (cols != 2) return fail("embedding wants [N][2] (id, punct)");
+        const int emb = (int)we->ne[0], pd = (int)pe->ne[0], Ed = emb + pd;
+        if (st->ne[1] < rows) return fail("sinusoid table has %lld rows < N=%d", (long long)st->ne[1], rows);
+        const float *wed = (const float *)we->data, *ped = (const float *)pe->data, *std_ = (const float *)st->data;
+        for (int i = 0; i < rows; i++)
+        {
+            const int id = (int)x[2 * i], pu = (int)x[2 * i + 1];
+            if (id < 0 || id >= we->ne[1] || pu < 0 || pu >= pe->ne[1]) return fail("id / punct out of range at %d", i);
+            memcpy(out + (size_t)i * Ed, wed + (size_t)id * emb, (size_t)emb * 4);
+            memcpy(out + (size_t)i * Ed + emb, ped + (size_t)pu * pd, (size_t)pd * 4);
+            for (int e = 0; e < Ed; e++) out[(size_t)i * Ed + e] = out[(size_t)i * Ed + e] + std_[(size_t)i * Ed + e];
+        }
+    }
     else
         return fail("unknown layer kind %d", kind);
     return rc;

@@ -83,7 +83,13 @@ void zvo_norm_rows(const float *x, int rows, int n, float eps, float *y);
 
 /* ---- one layer at a time (teacher-forced per-layer parity): x [rows][cols] time-major -> out time-major.
  * style / E: AdaIN style vector (decoder blocks 2..6); H: heads, ksz: FFN kernel sizes (encoder) or {vp_kernel} */
-enum { ZVO_LAYER_VOC_RESBLOCK = 0, ZVO_LAYER_ENC_FFT = 1, ZVO_LAYER_DEC_BLOCK = 2, ZVO_LAYER_VAR_PRED = 3 };
+enum { ZVO_LAYER_VOC_RESBLOCK = 0, ZVO_LAYER_ENC_FFT = 1, ZVO_LAYER_DEC_BLOCK = 2, ZVO_LAYER_VAR_PRED = 3,
+       ZVO_LAYER_VOC_UPSAMPLE = 4,   /* leaky_relu(0.1) + conv_transpose1d `index`: [L][Cin] -> [L*s][Cout] (src/hifigan.cpp:22-71,281-297) */
+       ZVO_LAYER_VOC_INPUT = 5,      /* (mel - mean) / scale + input conv k7: [T][80] -> [T][C0] (src/hifigan.cpp:242-265) */
+       ZVO_LAYER_VOC_OUTPUT = 6,     /* leaky_relu(0.01) + output conv k7 + tanh: [L][C] -> [L] (src/hifigan.cpp:324-345) */
+       ZVO_LAYER_DEC_ASR_RES = 7,    /* asr_res conv 1x1 + InstanceNorm: [T][E] -> [T][64] (src/stylettsdec.cpp:382-396) */
+       ZVO_LAYER_DEC_TO_OUT = 8,     /* to_out conv 1x1 + bias: [T][E] -> [T][80] (src/stylettsdec.cpp:432-441) */
+       ZVO_LAYER_ENC_EMBED = 9 };    /* word + punctuation embedding + positional encoding: [N][2] (id, punct as floats) -> [N][E] (src/fs2encoder.cpp:306-324) */
 int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int cols, const float *style, int E, int H,
               const int *ksz, float *out);
 

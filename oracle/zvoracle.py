@@ -169,13 +169,17 @@ class Oracle:
         return out
 
     LAYER_VOC_RESBLOCK, LAYER_ENC_FFT, LAYER_DEC_BLOCK, LAYER_VAR_PRED = 0, 1, 2, 3
+    LAYER_VOC_UPSAMPLE, LAYER_VOC_INPUT, LAYER_VOC_OUTPUT, LAYER_DEC_ASR_RES, LAYER_DEC_TO_OUT, LAYER_ENC_EMBED = 4, 5, 6, 7, 8, 9
 
-    def layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None, heads: int = 2, ksz=(9, 1)) -> np.ndarray:
+    def layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None, heads: int = 2, ksz=(9, 1),
+              out_rows: Optional[int] = None) -> np.ndarray:
         """one layer of the reference semantics on a given input (time-major [rows][cols]): HiFi-GAN residual block,
-        FFT block, decoder residual block, variance predictor (out_cols = 0 -> a vector of rows values)"""
+        FFT block, decoder residual block, variance predictor, transposed conv (out_rows = rows x scale), vocoder input /
+        output conv, asr_res, to_out, embedding (out_cols = 0 -> a vector of out_rows values)"""
         x = np.ascontiguousarray(x, dtype=np.float32)
         rows, cols = x.shape
-        out = np.empty((rows, out_cols) if out_cols else (rows,), np.float32)
+        orows = rows if out_rows is None else out_rows
+        out = np.empty((orows, out_cols) if out_cols else (orows,), np.float32)
         st = None if style is None else np.ascontiguousarray(style, dtype=np.float32)
         k = (C.c_int * 2)(*(list(ksz) + [1])[:2])
         self._chk(self.lib.zvo_layer(self.ctx, kind, index, _p(x), rows, cols, _p(st), 0 if st is None else len(st), heads, k, _p(out)))

@@ -110,6 +110,66 @@ def test_unknown_layers_are_errors(env):
     from zerovox_cpp_amd import capi
     m, g, t, o = env
     x = np.zeros((32, g.E), np.float32)
-    for kind, idx in ((m.LAYER_ENC_FFT, 99), (m.LAYER_DEC_BLOCK, 7), (9, 0)):
+    for kind, idx in ((m.LAYER_ENC_FFT, 99), (m.LAYER_DEC_BLOCK, 7), (m.LAYER_VOC_UPSAMPLE, 4), (99, 0)):
         with pytest.raises(capi.ZvError):
             m.debug_layer(kind, idx, x, g.E)
+
+
+# ---- round 3: the layers that only stage-level gates (at the noise floor) used to cover ------------------------------
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_every_transposed_conv(env, idx):
+    """leaky_relu(0.1) + conv_transpose1d (reference src/hifigan.cpp:22-71, 281-297; here a polyphase ordinary conv whose
+    channels-last output IS the up-sampled sequence), 48 frames at the stage's input rate"""
+    m, g, t, o = env
+    cin = g.voc_channels >> idx
+    cout, s = cin // 2, g.upsample_scales[idx]
+    rate_in = 1 if idx == 0 else m.voc_rate(idx - 1)
+    x = (0.7 * np.random.default_rng(400 + idx).standard_normal((48 * rate_in, cin))).astype(np.float32)
+    got = m.debug_layer(m.LAYER_VOC_UPSAMPLE, idx, x, cout, out_rows=x.shape[0] * s)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_UPSAMPLE, idx, x, cout, out_rows=x.shape[0] * s)
+    _check(f"conv_transpose1d {idx} ({cin}->{cout}, x{s})", got, ref, alt, 1e-4)
+
+
+def test_vocoder_input_conv(env):
+    """(mel - mean) / scale + input conv k7 (src/hifigan.cpp:242-265)"""
+    from zerovox_cpp_amd import synth
+    m, g, t, o = env
+    x = synth.vocoder_mel(g, t, 41, 96)
+    got = m.debug_layer(m.LAYER_VOC_INPUT, 0, x, g.voc_channels)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_INPUT, 0, x, g.voc_channels)
+    _check("vocoder input conv", got, ref, alt, 1e-4)
+
+
+def test_vocoder_output_conv_tanh(env):
+    """leaky_relu(0.01) + conv k7 (32 -> 1) + tanh (src/hifigan.cpp:324-345) on a given MRF mean"""
+    m, g, t, o = env
+    C = g.voc_channels >> len(g.upsample_scales)
+    x = (0.6 * np.random.default_rng(43).standard_normal((16 * g.hop_size, C))).astype(np.float32)
+    got = m.debug_layer(m.LAYER_VOC_OUTPUT, 0, x, 0)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_OUTPUT, 0, x, 0)
+    _check("vocoder output conv + tanh", got, ref, alt, 1e-4)
+
+
+def test_decoder_asr_res_and_to_out(env):
+    """asr_res = InstanceNorm(conv1x1(enc_seq)) (src/stylettsdec.cpp:382-396) and to_out = conv1x1 + bias (:432-441)"""
+    m, g, t, o = env
+    T = 96
+    x = (1.1 * np.random.default_rng(44).standard_normal((T, g.E))).astype(np.float32)
+    got = m.debug_layer(m.LAYER_DEC_ASR_RES, 0, x, g.residual_dim)
+    ref, alt = _oracle_pair(o, o.LAYER_DEC_ASR_RES, 0, x, g.residual_dim)
+    _check("decoder asr_res", got, ref, alt, 1e-4)
+    got = m.debug_layer(m.LAYER_DEC_TO_OUT, 0, x, g.num_mels)
+    ref, alt = _oracle_pair(o, o.LAYER_DEC_TO_OUT, 0, x, g.num_mels)
+    _check("decoder to_out", got, ref, alt, 1e-4)
+
+
+def test_encoder_embedding_is_bit_exact(env):
+    """word + punctuation embedding + positional encoding (src/fs2encoder.cpp:306-324): a gather and one f32 add per element"""
+    from zerovox_cpp_amd import synth
+    m, g, t, o = env
+    ids, puncts, _ = synth.encoder_inputs(g, 45, 200)
+    x = np.stack([ids, puncts], axis=1).astype(np.float32)
+    got = m.debug_layer(m.LAYER_ENC_EMBED, 0, x, g.E)
+    ref = o.layer(o.LAYER_ENC_EMBED, 0, x, g.E)
+    assert np.array_equal(got, ref)

@@ -184,3 +184,22 @@ def test_oracle_reproduces_reference_num_phonemes_below_max(ckpt):
     e = zvoracle.Oracle(tensors).encoder(g, ids, puncts, style, int(z["T"]), num_phonemes=int(z["num"]))
     assert e["n_frames"] == int(z["n_frames"]) and np.array_equal(e["hidden"], z["hidden"])
     assert np.array_equal(e["logdur"], z["logdur"]) and sha(e["features"]) == str(z["features_sha256"])
+
+
+def test_oracle_layers_compose_to_the_oracle_vocoder(tmp_path):
+    """zvo_layer's vocoder kinds (input conv, transposed convs, residual blocks, output conv: the per-layer checkers of
+    tests/test_gpu_layers.py) chained by hand reproduce zvo_vocoder — which reproduces the compiled reference — bit for bit"""
+    from zerovox_cpp_amd import gguf, synth
+    from oracle import zvoracle
+    g = synth.TINY
+    path = str(tmp_path / "tiny.gguf")
+    synth.write_checkpoint(path, g, 1234)
+    _, t = gguf.read_gguf(path)
+    o = zvoracle.Oracle(t)
+    mel = synth.vocoder_mel(g, t, 7, 16)
+    x = o.layer(o.LAYER_VOC_INPUT, 0, mel, g.voc_channels)
+    for i, s in enumerate(g.upsample_scales):
+        up = o.layer(o.LAYER_VOC_UPSAMPLE, i, x, x.shape[1] // 2, out_rows=x.shape[0] * s)
+        ys = [o.layer(o.LAYER_VOC_RESBLOCK, i * 3 + j, up, up.shape[1]) for j in range(3)]
+        x = ((ys[0] + ys[1]) + ys[2]) * np.float32(1.0 / np.float32(3))          # src/hifigan.cpp:300-315
+    assert np.array_equal(o.layer(o.LAYER_VOC_OUTPUT, 0, x, 0), o.vocoder(mel))

@@ -197,11 +197,14 @@ class Model:
         return mel
 
     LAYER_VOC_RESBLOCK, LAYER_ENC_FFT, LAYER_DEC_BLOCK, LAYER_VAR_PRED = 0, 1, 2, 3
+    LAYER_VOC_UPSAMPLE, LAYER_VOC_INPUT, LAYER_VOC_OUTPUT, LAYER_DEC_ASR_RES, LAYER_DEC_TO_OUT, LAYER_ENC_EMBED = 4, 5, 6, 7, 8, 9
 
-    def debug_layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None) -> np.ndarray:
-        """zv_debug_layer: one layer of the production schedule on the given input (time-major [rows][cin])"""
+    def debug_layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None, out_rows: Optional[int] = None) -> np.ndarray:
+        """zv_debug_layer: one layer of the production schedule on the given input (time-major [rows][cin]); out_rows when the
+        layer changes the rate (transposed conv: rows x scale)"""
         x = np.ascontiguousarray(x, dtype=np.float32)
-        out = np.empty((x.shape[0], out_cols) if out_cols else (x.shape[0],), np.float32)
+        orows = x.shape[0] if out_rows is None else out_rows
+        out = np.empty((orows, out_cols) if out_cols else (orows,), np.float32)
         st = None if style is None else np.ascontiguousarray(style, dtype=np.float32)
         self._chk(self.lib.zv_debug_layer(self.h, kind, index, _ptr(x), x.shape[0], _ptr(st), _ptr(out)))
         return out

@@ -617,19 +617,34 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
         M.dbg_layer.out = out;
         struct Reset { Model &M; ~Reset() { M.dbg_layer = Model::DebugLayer(); } } reset{M};
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        if (kind == ZV_LAYER_VOC_RESBLOCK)
+        if (kind == ZV_LAYER_VOC_RESBLOCK || kind == ZV_LAYER_VOC_UPSAMPLE || kind == ZV_LAYER_VOC_INPUT || kind == ZV_LAYER_VOC_OUTPUT)
         {
-            const int stage = index / (int)M.hp.voc_num_resblocks;
-            ZV_NEED(index >= 0 && stage < (int)M.hp.voc_num_upsamples, "residual block index out of range");
-            const uint32_t rate = (uint32_t)M.voc_stage_rate(stage);
-            ZV_NEED(rows % rate == 0, "rows must be a multiple of the stage's samples per frame");
+            // rows are rows at the layer's INPUT rate: frames x samples per frame of the stage the layer reads
+            uint32_t rate = 1;
+            if (kind == ZV_LAYER_VOC_RESBLOCK)
+            {
+                const int stage = index / (int)M.hp.voc_num_resblocks;
+                ZV_NEED(index >= 0 && stage < (int)M.hp.voc_num_upsamples, "residual block index out of range");
+                rate = (uint32_t)M.voc_stage_rate(stage);
+            }
+            else if (kind == ZV_LAYER_VOC_UPSAMPLE)
+            {
+                ZV_NEED(index >= 0 && index < (int)M.hp.voc_num_upsamples, "upsample index out of range");
+                rate = index == 0 ? 1u : (uint32_t)M.voc_stage_rate(index - 1);
+            }
+            else if (kind == ZV_LAYER_VOC_OUTPUT)
+                rate = (uint32_t)hop;
+            ZV_NEED(rows % rate == 0, "rows must be a multiple of the layer's samples per frame");
             const uint32_t T = rows / rate;
             check_T(M, T);
             char *io = (char *)M.io_scratch(al((size_t)T * Mm * 4) + (size_t)T * hop * 4);
-            ZV_HIP(hipMemsetAsync(io, 0, (size_t)T * Mm * 4, M.stream));
+            if (kind == ZV_LAYER_VOC_INPUT)
+                ZV_HIP(hipMemcpyAsync(io, x, (size_t)T * Mm * 4, hipMemcpyHostToDevice, M.stream));      // the layer's input IS the mel
+            else
+                ZV_HIP(hipMemsetAsync(io, 0, (size_t)T * Mm * 4, M.stream));
             M.vocode_dev(zv::Batch::single(1, T, 1), (const float *)io, (float *)(io + al((size_t)T * Mm * 4)));
         }
-        else if (kind == ZV_LAYER_ENC_FFT || kind == ZV_LAYER_VAR_PRED)
+        else if (kind == ZV_LAYER_ENC_FFT || kind == ZV_LAYER_VAR_PRED || kind == ZV_LAYER_ENC_EMBED)
         {
             const uint32_t n = rows, T = 8;
             char *io = (char *)M.io_scratch(256 + 2 * al((size_t)n * 4) + al(E * 4) + (size_t)T * E * 4);
@@ -637,17 +652,36 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
             int32_t *d_ids = (int32_t *)(io + 256), *d_pun = (int32_t *)(io + 256 + al((size_t)n * 4));
             float *d_sty = (float *)(io + 256 + 2 * al((size_t)n * 4)), *d_hid = (float *)((char *)d_sty + al(E * 4));
             ZV_HIP(hipMemsetAsync(io, 0, 256 + 2 * al((size_t)n * 4), M.stream));
+            std::vector<int32_t> hid, hpu;
+            if (kind == ZV_LAYER_ENC_EMBED)
+            {
+                // x[n] = (phoneme id, punctuation id) as floats
+                hid.resize(n);
+                hpu.resize(n);
+                for (uint32_t i = 0; i < n; i++)
+                {
+                    hid[i] = (int32_t)x[2 * i];
+                    hpu[i] = (int32_t)x[2 * i + 1];
+                }
+                check_ids(M, hid.data(), hpu.data(), n);
+                ZV_HIP(hipMemcpyAsync(d_ids, hid.data(), (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+                ZV_HIP(hipMemcpyAsync(d_pun, hpu.data(), (size_t)n * 4, hipMemcpyHostToDevice, M.stream));
+                ZV_HIP(hipStreamSynchronize(M.stream));            // the staging vectors go out of scope below
+            }
             ZV_HIP(hipMemcpyAsync(d_sty, sty, E * 4, hipMemcpyHostToDevice, M.stream));
             M.encode_dev(zv::Batch::single(n, T, n), d_ids, d_pun, d_sty, d_hid, d_nf);
         }
-        else if (kind == ZV_LAYER_DEC_BLOCK)
+        else if (kind == ZV_LAYER_DEC_BLOCK || kind == ZV_LAYER_DEC_ASR_RES || kind == ZV_LAYER_DEC_TO_OUT)
         {
             const uint32_t T = rows;
             check_T(M, T);
             const size_t b_hid = al((size_t)T * E * 4), b_sty = al(E * 4);
             char *io = (char *)M.io_scratch(b_hid + b_sty + (size_t)T * Mm * 4);
             float *d_sty = (float *)io, *d_hid = (float *)(io + b_sty), *d_mel = (float *)(io + b_sty + b_hid);
-            ZV_HIP(hipMemsetAsync(d_hid, 0, b_hid, M.stream));
+            if (kind == ZV_LAYER_DEC_ASR_RES)
+                ZV_HIP(hipMemcpyAsync(d_hid, x, (size_t)T * E * 4, hipMemcpyHostToDevice, M.stream));     // asr_res reads the stage input itself
+            else
+                ZV_HIP(hipMemsetAsync(d_hid, 0, b_hid, M.stream));
             ZV_HIP(hipMemcpyAsync(d_sty, sty, E * 4, hipMemcpyHostToDevice, M.stream));
             M.decode_dev(zv::Batch::single(1, T, 1), d_hid, d_sty, d_mel);
         }

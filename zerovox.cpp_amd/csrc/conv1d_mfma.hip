@@ -43,6 +43,12 @@ static constexpr int CK_MAX = 256;
 #ifndef ZV_STAGE_U
 #define ZV_STAGE_U 4
 #endif
+#ifndef ZV_STAGE_U128
+#define ZV_STAGE_U128 12
+#endif
+#ifndef ZV_STAGE_U256
+#define ZV_STAGE_U256 19
+#endif
 // waves per SIMD the 64 x 64 wave-tile instantiation of the generic conv kernel is compiled for (3: 168 registers)
 #ifndef ZV_NT2_OCC
 #define ZV_NT2_OCC 3
@@ -667,10 +673,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
     const int nicb = Cin_p >> 4;
     const int ntiles = (Cout_p + 31) >> 5;
-    const int nt0 = (blockIdx.y * WN + wn) * NT;
-    const bool n_ok = nt0 < ntiles && !is_loader;
-    // a wave whose second tile does not exist computes the last tile twice and stores it once
-    const int ntl = nt0 + NT <= ntiles ? nt0 : (ntiles - NT > 0 ? ntiles - NT : 0);
+    // the output tiles are dealt evenly over the gridDim.y channel groups (33 tiles over 5 groups: 7 7 7 6 6, not 8 8 8 8 1 —
+    // every workgroup stages its input tile for every chunk, however few of its waves have work)
+    const int gt0 = (int)((long)blockIdx.y * ntiles / gridDim.y), gt1 = (int)((long)(blockIdx.y + 1) * ntiles / gridDim.y);
+    const int nt0 = gt0 + wn * NT;
+    const bool n_ok = nt0 < gt1 && !is_loader;
+    // a wave whose second tile does not exist computes the tile before it twice and stores it once
+    const int ntl = nt0 + NT <= gt1 ? nt0 : (gt1 - NT > 0 ? gt1 - NT : 0);
     const int rows = BM + (K - 1) * dil;
     const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
 
@@ -766,7 +775,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
             if (J.pro == PRO_RAW_F16 && (ck & 7) == 0 && !SINGLE)
                 stage_raw16<(BM >= 64 ? 9 : 5), 256>(S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
             else
-                stage_tile<ZV_STAGE_U>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+                // (the big wave tiles have the registers — dead before the accumulators live — for 8 pieces in flight: a
+                // 64-row x 256-channel f32 tile in three round trips instead of five)
+                stage_tile<(MT * NT >= 4 && !SINGLE ? 8 : ZV_STAGE_U)>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         }
         __syncthreads();
 #ifdef ZV_STAMPS
@@ -1172,7 +1183,10 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     // every staging load of the tile is in flight before the first one is consumed (one HBM round trip instead of one
     // per batch of four: measured 6.7 of a workgroup's 20.5 us at 64 channels)
     // (the merged variant holds the running sum of the branches: it keeps the short batches and its occupancy)
-    constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : 4));
+    // (the wide stages: phase stamps, round 3 — with 4 pieces in flight a 128-channel tile took 6 round trips = 9.7 us of a
+    // workgroup's 35, a 256-channel tile 10 = 16 us of 82; the staging registers are dead before the accumulators live, so
+    // 12 / 19 in flight cost no occupancy)
+    constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : (CP == 128 ? ZV_STAGE_U128 : ZV_STAGE_U256)));
     // (the wide stages keep their registers for occupancy: their first fragments are requested right before the loops)
     constexpr bool EARLY_B = CP <= 64 && !MERGE;
     half8 bw[4][NT];
@@ -1633,7 +1647,9 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil.  The loop walks
     // whole taps once a tap is at least a body (CP >= 128): K + 1 taps (51 KB for the 128-channel stage: room for three
     // workgroups per CU instead of two — measured worth 0.6 %)
-    const size_t lds = (size_t)(BM + (Kmax + (CP >= 128 ? 1 : 4)) * dmax) * (CP * 2 + 16);
+    // (CP = 256: exactly K taps — the prefetch one tap past the end reads rows that exist but are never used — so that the
+    // 96-row tile of MT = 3 stays under 80 KB: two workgroups per CU)
+    const size_t lds = (size_t)(BM + (Kmax + (CP == 256 ? 0 : (CP >= 128 ? 1 : 4))) * dmax) * (CP * 2 + 16);
     auto kern = resblock_pair_kernel<CP, MT, MERGE>;
     if (lds > 64 * 1024)
     {
@@ -1694,13 +1710,17 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
         }
     }
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
-    if (mt_env == 2 || mt_env == 4) MT = mt_env;
+    // 256 channels, batches: 96-row tiles (two thirds of the weight-fragment traffic per row, 10 instead of 16 % of conv2 spent
+    // on halo rows at 11 taps; 80 KB of LDS and 234 registers still give two workgroups per CU): 1 010 -> 897 us per launch.
+    // (The merged form would need 330 registers.)
+    if (Cp == 256 && !merge_out && wgs(3) >= 4L * n_cu) MT = 3;
+    if (mt_env == 2 || mt_env == 4 || (mt_env == 3 && Cp == 256 && !merge_out)) MT = mt_env;      // (the merged form of MT = 3 needs 330 registers)
     js.kmax = Kmax;
 #define ZV_PCASE(cp, mt)                                                                                 \
     if (Cp == cp && MT == mt)                                                                            \
         return merge_out ? launch_pair_cfg<cp, mt, true>(s, js, njobs, Lmax, Kmax, dmax)                 \
                          : launch_pair_cfg<cp, mt, false>(s, js, njobs, Lmax, Kmax, dmax);
-    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2) ZV_PCASE(256, 4)
+    ZV_PCASE(32, 4) ZV_PCASE(32, 2) ZV_PCASE(64, 4) ZV_PCASE(64, 2) ZV_PCASE(128, 4) ZV_PCASE(128, 2) ZV_PCASE(256, 2) ZV_PCASE(256, 3) ZV_PCASE(256, 4)
 #undef ZV_PCASE
     return hipErrorInvalidValue;
 }

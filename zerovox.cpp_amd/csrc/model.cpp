@@ -833,6 +833,11 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
         j.pb = voc_.scale;
         j.out = c0;
         conv(&j, 1, fr, rate, "voc_input_conv", conv_bytes(La, M, C, j.K, false), conv_flops(La, M, C, j.K));
+        if (dbg_layer.kind == ZV_LAYER_VOC_INPUT)
+        {
+            dbg_extract(c0, voc_.in_conv.Cout_p, C, L);
+            return;
+        }
     }
 
     char *pool_base[2];
@@ -878,10 +883,25 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             if (i == 0) { j.x0 = c0; j.pro = PRO_ACT; }
             else if (prev_merged) { j.x0 = prev_merged; j.pro = PRO_SCALE_ACT; j.pscale = third; }
             else { j.x0 = prev_y[0]; j.x1 = prev_y[1]; j.x2 = prev_y[2]; j.pro = PRO_SUM3_ACT; j.pscale = third; }
+            const bool dbg_up = dbg_layer.kind == ZV_LAYER_VOC_UPSAMPLE && dbg_layer.index == i;
+            if (dbg_up)
+            {
+                // the layer's input is what enters leaky_relu (src/hifigan.cpp:281): the input conv's output / the MRF mean
+                float *in = i == 0 ? c0 : const_cast<float *>(prev_merged ? prev_merged : prev_y[0]);
+                dbg_inject(in, up.Cin_p, C, L);
+                j.x0 = in;
+                j.x1 = j.x2 = nullptr;
+                if (i > 0) { j.pro = PRO_SCALE_ACT; j.pscale = 1.0f; }
+            }
             j.out = ub;
             // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
             conv(&j, 1, fr, rate, "voc_upsample", 4.0 * La * C * (i == 0 ? 1 : 3) + 4.0 * La * s * Cout + 2.0 * C * Cout * 2 * s,
                  2.0 * La * C * Cout * 2 * s);
+        }
+        if (dbg_layer.kind == ZV_LAYER_VOC_UPSAMPLE && dbg_layer.index == i)
+        {
+            dbg_extract(ub, Cp, Cout, Lo);
+            return;
         }
         skip_launch_ = (part == 1 && last_stage) || (part == 2 && !last_stage);
         L = Lo;
@@ -1000,7 +1020,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             // spare: at one round (a single 512-frame utterance) the merged 128- / 64-channel launches took 45.7 / 37.3 us against
             // 28.4 / 32.8 us for the three branches side by side, more than the upsample conv gains from reading one tensor
             const int merge_tile = Cp >= 256 ? 54 : (Cp == 128 ? 118 : 246);
-            const bool merge_pays = knob(ZV_MERGE_ALWAYS) != 0 || Lbatch / merge_tile >= 4L * n_cu;
+            const bool merge_pays = knob(ZV_MERGE_ALWAYS) != 0 || (Lbatch / merge_tile >= 4L * n_cu && Cp <= knob(ZV_MERGE_MAXC));
             const bool merge = fused && !no_merge_ && !dbg_here && d == voc_.n_dil - 1 && merge_pays;
             if (merge)
             {
@@ -1049,7 +1069,16 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
         a.out = d_wav;
         a.segs = fr;
         a.rate = rate;
+        if (dbg_layer.kind == ZV_LAYER_VOC_OUTPUT)
+        {
+            // the layer's input is the MRF mean that enters leaky_relu(0.01) (src/hifigan.cpp:315-324)
+            float *in = const_cast<float *>(a.x0);
+            dbg_inject(in, a.ldx, C, L);
+            a.x1 = a.x2 = nullptr;
+            a.pscale = 1.0f;
+        }
         ZV_LAUNCH("voc_output_conv", 12.0 * La * C + 4.0 * La, 2.0 * La * C * a.K, launch_out_conv(stream, a));
+        if (dbg_layer.kind == ZV_LAYER_VOC_OUTPUT) dbg_extract(d_wav, 1, 1, L);
     }
 }
 
@@ -1299,6 +1328,11 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         ZV_LAUNCH("dec_norm_apply", 8.0 * Ld * R, 3.0 * Ld * R,
                   launch_norm_apply(stream, asr_t, R, R, st_a, ss, dec_.asr1w, dec_.asr1b, cat + B, CAT, part_t, nblk, fr));
         finalize(part_t, R, st_x, B);            // statistics of the concat's asr columns: final for decode0..2
+        if (dbg_layer.kind == ZV_LAYER_DEC_ASR_RES)
+        {
+            dbg_extract(cat + B, CAT, R, L);
+            return;
+        }
     }
 
     // decode0..4: AdainResBlk1d; blocks 0..2 read cat([x, asr]) and 0,1 write x back into it   (:406-428).  The x
@@ -1324,7 +1358,9 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         j.ldx = ldc;
         j.out = d_mel;
         j.ldo = dec_.M;
+        if (dbg_layer.kind == ZV_LAYER_DEC_TO_OUT) dbg_inject(const_cast<float *>(cur), ldc, Ed, L);
         conv(&j, 1, fr, 1, "dec_conv", conv_bytes(Ld, Ed, dec_.M, 1, false), conv_flops(Ld, Ed, dec_.M, 1));
+        if (dbg_layer.kind == ZV_LAYER_DEC_TO_OUT) dbg_extract(d_mel, dec_.M, dec_.M, L);
     }
 }
 
@@ -1362,6 +1398,11 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
 
     ZV_LAUNCH("enc_embed", 8.0 * nd * Ed, 1.0 * nd * Ed,
               launch_embed(stream, d_ids, d_puncts, enc_.wemb, hp.emb_dim, enc_.pemb, hp.punct_emb_dim, enc_.posenc, x, Ed, tk));
+    if (dbg_layer.kind == ZV_LAYER_ENC_EMBED)
+    {
+        dbg_extract(x, Ed, Ed, n);
+        return t;
+    }
     const float temperature = (float)pow((double)dk, 0.5);               // src/fs2encoder.cpp:66
     const float inv_t = (float)(1.0 / temperature);                      // :107
     int layer_no = 0;
