@@ -79,6 +79,11 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
             assert np.array_equal(model.decode(hid, style), mel), ("loader waves", v)
         with capi.switches(ZV_DEC_PREPASS=v, ZV_CONV_SINGLE=0):
             assert np.array_equal(model.decode(hid, style), mel), ("no single loop", v)
+    # the batches' 256 x 256-tile GEMM form of the wide convs (both operands through LDS by LDS-DMA, taps folded into the K loop)
+    with capi.switches(ZV_DEC_PREPASS=1, ZV_CONV_GEMM=2):
+        assert np.array_equal(model.decode(hid, style), mel), "conv_gemm_kernel"
+    with capi.switches(ZV_DEC_PREPASS=1, ZV_CONV_GEMM=0):
+        assert np.array_equal(model.decode(hid, style), mel), "no conv_gemm_kernel"
 
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])

@@ -95,6 +95,9 @@ def test_every_decoder_residual_block(env, block):
             got = m.debug_layer(m.LAYER_DEC_BLOCK, block, x, cout, style=style)
         ref, alt = _oracle_pair(o, o.LAYER_DEC_BLOCK, block, x, cout, style=style)
         _check(f"decoder block {block} ({cin}->{cout}) prepass={pre}", got, ref, alt, 3e-4)
+        if pre:
+            with capi.switches(ZV_DEC_PREPASS=1, ZV_CONV_GEMM=2):      # the batch form of the wide convs on this 96-frame block
+                assert np.array_equal(m.debug_layer(m.LAYER_DEC_BLOCK, block, x, cout, style=style), got), "conv_gemm_kernel"
 
 
 @pytest.mark.parametrize("p", [0, 1, 2])

@@ -675,7 +675,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     const int ntiles = (Cout_p + 31) >> 5;
     // the output tiles are dealt evenly over the gridDim.y channel groups (33 tiles over 5 groups: 7 7 7 6 6, not 8 8 8 8 1 —
     // every workgroup stages its input tile for every chunk, however few of its waves have work)
-    const int gt0 = (int)((long)blockIdx.y * ntiles / gridDim.y), gt1 = (int)((long)(blockIdx.y + 1) * ntiles / gridDim.y);
+    const int nt_span = ntiles - jobs.nt_begin;     // (tiles before nt_begin belong to conv_gemm_kernel)
+    const int gt0 = jobs.nt_begin + (int)((long)blockIdx.y * nt_span / gridDim.y), gt1 = jobs.nt_begin + (int)((long)(blockIdx.y + 1) * nt_span / gridDim.y);
     const int nt0 = gt0 + wn * NT;
     const bool n_ok = nt0 < gt1 && !is_loader;
     // a wave whose second tile does not exist computes the tile before it twice and stores it once
@@ -890,7 +891,7 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
-    const int ntiles = (Cout_p + 31) / 32;
+    const int ntiles = (Cout_p + 31) / 32 - jobs.nt_begin;
     jobs.tps = (Lmax + BM - 1) / BM;
     dim3 grid(jobs.tps * jobs.segs.nseg, (ntiles + WN * NT - 1) / (WN * NT), njobs);
 #ifdef ZV_STAMPS
@@ -910,14 +911,53 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     return hipGetLastError();
 }
 
+static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs &segs, int rate);
+
+static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, int nt_begin);
+
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
     if (njobs < 1 || njobs > CONV_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
+    // batches of wide convs over an f16 operand tensor (the decoder's, behind its pre-pass): whole groups of 8 output tiles
+    // on conv_gemm_kernel, job by job; the tiles left over (1 056 channels = 4 groups + 1 tile) on the kernel below
+    {
+        const int g_env = knob(ZV_CONV_GEMM);
+        const long rows = (long)segs.max_rows * rate * segs.nseg;
+        ConvJob rest[CONV_MAX_JOBS];
+        int nrest = 0, ngemm = 0;
+        for (int i = 0; i < njobs; i++)
+        {
+            const ConvJob &j = jobs[i];
+            const bool ok = g_env != 0 && (g_env == 2 || rows >= 16384) && j.w8 && j.pro == PRO_RAW_F16 && j.Cin_p >= 256 &&
+                            conv_gemm_groups(j.Cout_p) >= 1 && !j.out_f16 && (j.ldx & 7) == 0;
+            if (!ok)
+            {
+                rest[nrest++] = j;
+                continue;
+            }
+            ngemm++;
+            hipError_t e = launch_conv_gemm(s, j, segs, rate);
+            if (e != hipSuccess) return e;
+            const int done = conv_gemm_tiles(j.Cout_p);
+            if (done * 32 < j.Cout_p)
+            {
+                e = launch_conv_from(s, &j, 1, n_cu, segs, rate, done);
+                if (e != hipSuccess) return e;
+            }
+        }
+        if (ngemm) return nrest ? launch_conv_from(s, rest, nrest, n_cu, segs, rate, 0) : hipSuccess;
+    }
+    return launch_conv_from(s, jobs, njobs, n_cu, segs, rate, 0);
+}
+
+static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, int nt_begin)
+{
     const int dbg = knob(ZV_DBG);
     ConvJobs js;
     js.segs = segs;
     js.rate = rate;
     js.tps = 0;
+    js.nt_begin = nt_begin;
     const int Lmax = segs.max_rows * rate;
     int halo = 0, ck = 0, dmax = 1;
     for (int i = 0; i < njobs; i++)
@@ -933,7 +973,8 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
     }
     for (int i = njobs; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     const int Cout_p = jobs[0].Cout_p;
-    const int ntiles = (Cout_p + 31) / 32;
+    const int ntiles = (Cout_p + 31) / 32 - nt_begin;
+    if (ntiles < 1) return hipErrorInvalidValue;
     // three output tiles already take four waves (one idles): the input tile is staged once instead of twice
     const int WN = ntiles >= 3 ? 4 : (ntiles >= 2 ? 2 : 1);
     // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups; the tile
@@ -2277,6 +2318,379 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
 #undef ZV_TCASE
     return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_gemm_kernel — the wide convs of a batch over an f16 operand tensor (StyleTTS decoder behind its operand pre-pass,
+// reference src/stylettsdec.cpp:69-149,242-304: ggml_conv_1d = im2col(F16) + mul_mat) as a 256 x 256-tile GEMM.
+//
+// conv1d_mfma_kernel streams every weight fragment global -> registers once per wave (1 KiB per two MFMAs at its 64-row wave
+// tiles: the CU's whole 64 B/clk vector-memory path at the matrix pipe's full rate) and restages its input tile for every
+// 256-channel chunk between its MFMA loops.  Here
+//   * a workgroup is 8 waves (2 along time x 4 along channels), each owns 128 rows x 64 output channels = 4 x 2 MFMA tiles:
+//     128 accumulator registers, one B fragment feeds four MFMAs, one A fragment two;
+//   * BOTH operands reach LDS by LDS-DMA (buffer_load ... lds, no registers, no VALU): per step of the K loop ("unit" =
+//     (256-channel chunk, tap, 64-channel block)) the workgroup moves a 256-row x 64-channel slice of the operand tensor — the
+//     rows shifted by tap * dil: the im2col is the DMA's address arithmetic, rows outside the utterance are outside the
+//     buffer descriptor and arrive as zeros — and the 64 x 256 block of weights, 32 KiB each, into one of two 64-KiB buffers,
+//     while the MFMAs of the previous unit run (one barrier per unit);
+//   * the operand tile's 16-byte pieces are XOR-swizzled by row (slot = piece ^ ((row >> 1) & 7)) on the SOURCE side of the DMA
+//     and on the ds_read_b128 side, so fragment reads are bank-conflict free without padding.
+// Units walk (chunk, tap, channel) in conv1d_mfma_kernel's order — 64-channel blocks of a chunk inside a tap — so every
+// output element is the same accumulation chain: same bits as every other regime.  Channels past Cin_p inside the last block
+// read finite neighbours (the next row) against zero weights.
+int conv_gemm_groups(int Cout_p) { return ((Cout_p + 31) / 32) / 8; }
+// tiles the kernel covers: whole groups of 8, plus ONE leftover tile (1 056 channels = 33 tiles, 528 = 17) that the last group's
+// workgroups compute on the side (one extra 32 x 32 tile per wave); more leftovers stay with conv1d_mfma_kernel
+int conv_gemm_tiles(int Cout_p)
+{
+    const int nt = (Cout_p + 31) / 32, ng = nt / 8;
+    return ng * 8 + ((nt - ng * 8 == 1 && ng >= 1) ? 1 : 0);
+}
+
+__device__ __forceinline__ int Cout_p_groups(int Cout_p) { return ((Cout_p + 31) >> 5) >> 3; }
+
+__device__ __forceinline__ int conv_gemm_units_dev(int Cin_p, int K)
+{
+    const int full = Cin_p >> 8, rem = Cin_p & 255;
+    return K * (full * 4 + ((rem + 63) >> 6));
+}
+
+int conv_gemm_units(int Cin_p, int K)
+{
+    int n = 0;
+    for (int c0 = 0; c0 < Cin_p; c0 += 256) n += K * ((std::min(256, Cin_p - c0) + 63) / 64);
+    return n;
+}
+
+size_t conv_gemm_weight_halfs(int Cin_p, int Cout_p, int K)
+{
+    return (size_t)conv_gemm_tiles(Cout_p) * conv_gemm_units(Cin_p, K) * 2048;      // 4 fragments of 512 halfs per (unit, tile)
+}
+
+void pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst)
+{
+    const int ng = conv_gemm_groups(Cout_p), nu = conv_gemm_units(Cin_p, K), ntk = conv_gemm_tiles(Cout_p);
+    size_t gbase = 0;                                // halfs before group g
+    for (int g = 0; g < ng; g++)
+    {
+        const int ntg = (g == ng - 1) ? ntk - 8 * g : 8;          // 8, or 9 in the last group
+        int u = 0;
+        for (int c0 = 0; c0 < Cin_p; c0 += 256)
+        {
+            const int nsub = (std::min(256, Cin_p - c0) + 63) / 64;
+            for (int tap = 0; tap < K; tap++)
+                for (int sub = 0; sub < nsub; sub++, u++)
+                    for (int st = 0; st < 4; st++)
+                        for (int nt = 0; nt < ntg; nt++)
+                        {
+                            uint16_t *d = dst + gbase + (((size_t)u * 4 + st) * ntg + nt) * 512;
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int j = 0; j < 8; j++)
+                                {
+                                    const int oc = (g * 8 + nt) * 32 + (lane & 31);
+                                    const int ic = c0 + sub * 64 + st * 16 + 8 * (lane >> 5) + j;
+                                    d[lane * 8 + j] = (oc < OC && ic < IC) ? w[((size_t)oc * IC + ic) * K + tap] : (uint16_t)0;
+                                }
+                        }
+        }
+        gbase += (size_t)nu * 4 * ntg * 512;
+    }
+}
+
+// one 1-KiB piece global -> LDS: lane i lands at lds_base + 16 * i.  The DMA is invisible to hipcc (which would answer a
+// visible one with vmcnt(0) in front of every LDS read): the kernel counts it by hand.  M0 carries the LDS address and is
+// restored (cdna_hip_programming.md §5.7); s_nop 4: the descriptor / M0 may have been written by the instructions just before.
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_piece(u32x4s rsrc, unsigned lds_base, unsigned voff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+
+__device__ __forceinline__ u32x4s make_rsrc(const void *base, unsigned bytes)
+{
+    const uint64_t a = (uint64_t)base;
+    u32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);      // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// EXTRA: the last group's workgroups, which also own the conv's ninth leftover tile (one more 32 x 32 tile per wave).  Two
+// instantiations behind one launch: the 8-tile path keeps its own schedule and registers.
+template <bool EXTRA>
+__device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g, const int rt)
+{
+    // The K loop runs in HALF units (32 channels = two k16 steps: a 256-row x 64-byte operand slice + the 2 x ntg weight
+    // fragments) through a ring of four LDS slots: half h is consumed while h + 1 and h + 2 are in flight and h + 3 is being
+    // requested (the first form — whole units, two buffers, one unit ahead — ran at the DMA's latency: 64 KiB requested and
+    // waited for per 1.1 us of MFMAs took 2.1 us).  One barrier per half unit; the waits are counted (vmcnt(8) leaves two
+    // halves in flight), never 0 inside the loop.
+    constexpr int BM = 256, UNIT = 32768;            // bytes of an 8-tile unit's weight block
+    constexpr int ntg = EXTRA ? 9 : 8;
+    constexpr int AH = 16384, BH = ntg * 2048;       // bytes of a half unit's operand slice / weight fragments
+    constexpr int SLOT = AH + 18432;                 // one ring slot (room for 9 tiles)
+    const ConvJob &J = jobs.j[0];
+    const int ng = (Cout_p_groups(J.Cout_p));
+    const int useg = rt / jobs.tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int m0 = (rt - useg * jobs.tps) * BM;
+    if (m0 >= L) return;
+    const size_t row0 = (size_t)sg.row0 * jobs.rate;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];     // [4 slots][A 16 KiB | B 16 (18) KiB]
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, ldx = J.ldx;
+    const int nunits = conv_gemm_units_dev(Cin_p, K), nhalf = 2 * nunits;
+    constexpr int bunit = ntg * 4096;                // bytes of one unit's weight block
+
+    // descriptors: the utterance's rows of the operand tensor (anything outside reads as zero = the conv's zero padding) and
+    // this group's weight stream (groups before the last one have 8 tiles)
+    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (unsigned)((size_t)L * ldx * 2));
+    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (unsigned)((size_t)nunits * bunit));
+
+    // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
+    // slot); the slot holds the 16-byte piece (slot ^ ((row >> 2) & 3)) of the row's 64 bytes
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+    {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ ((row >> 2) & 3);
+        a_voff[i] = ((m0 - J.pad + row) * ldx + piece * 8) * 2;
+    }
+
+    // half-unit walk: (chunk, tap, 64-channel block of the chunk, half)
+    int uc0 = 0, utap = 0, usub = 0, unsub = (min(256, Cin_p) + 63) >> 6, uh = 0;
+    unsigned i_abase = 0;
+    int i_aoff = 0, i_boff = 0;
+    auto issue_begin = [&](int h) {
+        i_abase = lds0 + (h & 3) * SLOT;
+        i_aoff = (utap * dil * ldx + uc0 + usub * 64 + uh * 32) * 2;
+        i_boff = (h >> 1) * bunit + (h & 1) * BH;
+        if (++uh == 2)
+        {
+            uh = 0;
+            if (++usub == unsub)
+            {
+                usub = 0;
+                if (++utap == K)
+                {
+                    utap = 0;
+                    uc0 += 256;
+                    unsub = (min(256, Cin_p - uc0) + 63) >> 6;
+                }
+            }
+        }
+    };
+    // per half and wave: two operand pieces, two weight fragments (+ one more for waves 0 and 1 where a ninth tile rides along:
+    // 18 fragments); the same count in every half, so the counted waits below hold
+    auto issue_part = [&](int i) {
+        dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff));
+        dma_piece(rs_b, i_abase + AH + (wave * 2 + i) * 1024, (unsigned)(i_boff + (wave * 2 + i) * 1024 + lane * 16));
+    };
+    auto issue_x = [&]() {
+        if (EXTRA && wave < 2) dma_piece(rs_b, i_abase + AH + (16 + wave) * 1024, (unsigned)(i_boff + (16 + wave) * 1024 + lane * 16));
+    };
+    const bool five = EXTRA && wave < 2;             // this wave requests five pieces per half
+
+    // fragment addresses inside a slot: A (mt, step): row wm*128 + mt*32 + (lane & 31), piece 2*step + (lane >> 5), swizzled;
+    // B (nt, step): fragment step*ntg + wn*2 + nt
+    const int swz = ((lane & 31) >> 2) & 3, hh = lane >> 5;
+    int a_rd[2], ax_rd[2];
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+    {
+        a_rd[st] = (wm * 128 + (lane & 31)) * 64 + (((2 * st + hh) ^ swz) << 4);
+        ax_rd[st] = (wave * 32 + (lane & 31)) * 64 + (((2 * st + hh) ^ swz) << 4);      // the ninth tile: rows wave * 32 ...
+    }
+    const int b_rd = AH + wn * 2048 + lane * 16;
+    constexpr int b_st = ntg * 1024;
+
+    floatx16 acc[4][2];
+    floatx16 accx;
+#pragma unroll
+    for (int r = 0; r < 16; r++) accx[r] = 0.f;
+    // prologue: halves 0, 1, 2 requested
+#pragma unroll
+    for (int h = 0; h < 3; h++)
+        if (h < nhalf)
+        {
+            issue_begin(h);
+            issue_part(0);
+            issue_part(1);
+            issue_x();
+        }
+    for (int h = 0; h < nhalf; h++)
+    {
+        // half h has landed for this wave once at most the pieces of h + 1 and h + 2 are outstanding; after the barrier it has
+        // for every wave, and every wave is done reading slot (h - 1) & 3 = (h + 3) & 3: half h + 3 can go there
+        const int ahead = min(2, nhalf - 1 - h);     // halves requested beyond h
+        if (ahead == 2)
+        {
+            if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        else if (ahead == 1)
+        {
+            if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool more = h + 3 < nhalf;
+        if (more) issue_begin(h + 3);
+        const char *buf = smem + (h & 3) * SLOT;
+        half8 a[2][4], b[2][2], ax[2], bx[2];
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+        {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) a[st][mt] = *(const half8 *)(buf + a_rd[st] + mt * 2048);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) b[st][nt] = *(const half8 *)(buf + b_rd + st * b_st + nt * 1024);
+            if constexpr (EXTRA)
+            {
+                ax[st] = *(const half8 *)(buf + ax_rd[st]);
+                bx[st] = *(const half8 *)(buf + AH + st * b_st + 8 * 1024 + lane * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (h == 0)
+            mfma_step<4, 2, false, true>(acc, a[0], b[0]);
+        else
+            mfma_step<4, 2, false>(acc, a[0], b[0]);
+        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[0], bx[0], accx, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue_part(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<4, 2, false>(acc, a[1], b[1]);
+        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[1], bx[1], accx, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more)
+        {
+            issue_part(1);
+            issue_x();
+        }
+    }
+    constexpr bool extra = EXTRA;
+
+    // ---- epilogue: bias, residual, scale, activation, f32 store, InstanceNorm partial sums (as conv1d_mfma_kernel) ----
+    const int Cout_p = J.Cout_p;
+    const float escale = J.escale;
+    const bool has_res = J.res != nullptr;
+    const float *res = has_res ? J.res + row0 * J.ldres : nullptr;
+    float *out = (float *)J.out + row0 * J.ldo;
+    auto finish_tile = [&](const floatx16 &tile, int t_first, int oc, int blk) {
+        if (oc >= Cout_p) return;
+        const float bias = J.bias ? J.bias[oc] : 0.f;
+        float resv[16];
+        if (has_res)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int t = t_first + (r & 3) + 8 * (r >> 2);
+                resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
+            }
+        }
+        float outv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const int t = t_first + (r & 3) + 8 * (r >> 2);
+            float v = tile[r] + bias;
+            if (has_res) v = v + resv[r];
+            v = v * escale;
+            if (J.eact) v = lrelu(v, J.oslope);
+            outv[r] = v;
+            if (t < L) __builtin_nontemporal_store(v, out + (size_t)t * J.ldo + oc);
+        }
+        if (J.stat_part && oc < J.stat_C && blk * 32 < L)
+            tile_stats_store(outv, t_first, L, J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc) * 2);
+    };
+    const int tbase = m0 + wm * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            finish_tile(acc[mt][nt], tbase + mt * 32, ((g * 8 + wn * 2 + nt) << 5) + (lane & 31), (m0 >> 5) + wm * 4 + mt);
+    if (extra) finish_tile(accx, m0 + wave * 32 + 4 * (lane >> 5), ((g * 8 + 8) << 5) + (lane & 31), (m0 >> 5) + wave);
+}
+
+
+__global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvJobs jobs)
+{
+    const ConvJob &J = jobs.j[0];
+    // workgroup -> (group of 8 output tiles, row tile), XCD-aware: workgroups are dealt round-robin over the 8 XCDs (observed, only
+    // the speed depends on it), each with its own 4-MiB L2.  A group's weight stream is 1.7 MB for a 1 056-channel conv, all four
+    // groups' 6.7 MB: an XCD that works on ONE group keeps its weights in L2, one that works on all of them fetches every block
+    // from the Infinity Cache (measured: 2.2 us per unit = 29 GB/s per CU, that cache's rate, against 1.1 us of MFMAs).
+    const int ng = (Cout_p_groups(J.Cout_p));
+    const int rts = jobs.tps * jobs.segs.nseg;
+    int g, rt;
+    if (jobs.nt_begin == 1 && (ng == 1 || ng == 2 || ng == 4))        // (nt_begin carries the order in this kernel: A/B hook)
+    {
+        // XCD-aware: one group per XCD (its weight stream stays in that L2).  Measured: no faster than the plain order.
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / ng;
+        g = xcd % ng;
+        rt = idx * per + xcd / ng;
+    }
+    else if (jobs.nt_begin == 2 && ng > 1)
+    {
+        // longest jobs first: the last group may carry a ninth tile (+ 12 % work); dispatched first, its workgroups are paired
+        // with 8-tile ones on their CUs by the dispatcher (two workgroups per CU and launch: 9 + 8 instead of 9 + 9)
+        if ((int)blockIdx.x < rts) { g = ng - 1; rt = blockIdx.x; }
+        else { const int b2 = blockIdx.x - rts; g = b2 % (ng - 1); rt = b2 / (ng - 1); }
+    }
+    else
+    {
+        g = blockIdx.x % ng;
+        rt = blockIdx.x / ng;
+    }
+    if (rt >= rts) return;
+    const bool ninth = g == ng - 1 && ((J.Cout_p + 31) >> 5) - 8 * ng == 1;
+    if (ninth)
+        conv_gemm_body<true>(jobs, g, rt);
+    else
+        conv_gemm_body<false>(jobs, g, rt);
+}
+
+static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs &segs, int rate)
+{
+    ConvJobs js;
+    js.j[0] = job;
+    for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = job;
+    js.segs = segs;
+    js.rate = rate;
+    js.nt_begin = knob(ZV_GEMM_ORDER);
+    const int Lmax = segs.max_rows * rate;
+    js.tps = (Lmax + 255) / 256;
+    if (job.stat_part && job.stat_nblk * 32 < Lmax) return hipErrorInvalidValue;
+    const int ng = conv_gemm_groups(job.Cout_p), rts = js.tps * segs.nseg;
+    // (grid.x covers (row tile, group) in the kernel's XCD-aware order: 8 / ng XCDs per group)
+    const dim3 grid((js.nt_begin == 1 && (ng == 1 || ng == 2 || ng == 4)) ? round_up(rts, 8 / ng) * ng : rts * ng, 1, 1);
+    const int lds = 4 * (16384 + 18432);
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)conv_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(512), lds, s, js);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

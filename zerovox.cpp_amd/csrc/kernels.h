@@ -93,6 +93,7 @@ struct ConvJob
     int          ck;             // input-channel chunk staged per LDS pass (set at pack time)
     // weights packed in MFMA-fragment order (see pack_conv_weight), bias padded to 32*ntiles
     const void  *w;
+    const void  *w8;             // the same weights in conv_gemm_kernel's stream order (pack_conv_weight_gemm), or null
     const float *bias;
     // epilogue: v = acc + bias; v += res; v *= escale; v = lrelu(v, oslope) if eact; store f32 | f16
     const float *res;
@@ -119,6 +120,7 @@ struct ConvJobs
     Segs    segs;
     int     rate;                // rows per base row of this launch
     int     tps;                 // row tiles per segment (grid.x = tps * nseg)
+    int     nt_begin;            // first output tile of this launch (the tiles before it belong to conv_gemm_kernel)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
@@ -130,6 +132,14 @@ size_t packed_conv_weight_halfs(int Cin_p, int Cout_p, int K);
 int    conv_pick_ck(int Cin_p, int ck_max = 0);
 // host-side repack of a GGUF conv weight (ggml ne [K, IC, OC], f16, k fastest) into fragment order
 void   pack_conv_weight(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, int ck, uint16_t *dst);
+// conv_gemm_kernel (batches of wide f16-operand convs): [group of 8 output tiles][unit = (256-chunk, tap, 64-channel block)][k16 step 4]
+// [tile 8][lane][8 halfs]: one unit = 32 KiB contiguous = what one workgroup moves into LDS per step of its K loop.  Only whole
+// groups of 8 tiles are packed (conv_gemm_groups); the remaining tiles run on conv1d_mfma_kernel.
+int    conv_gemm_groups(int Cout_p);
+int    conv_gemm_tiles(int Cout_p);         // output tiles conv_gemm_kernel covers (whole groups of 8, + one leftover tile)
+int    conv_gemm_units(int Cin_p, int K);
+size_t conv_gemm_weight_halfs(int Cin_p, int Cout_p, int K);
+void   pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst);
 // all jobs of one launch share the segments, Cout_p and the tile configuration; job.L is ignored (rows come from segs)
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
@@ -234,10 +244,11 @@ hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, cons
 
 // y = f16(lrelu(((x - mean) * rstd) * g + b, slope)) for C channels (a multiple of 4): the PRO_NORM_ACT operand written out
 // once (PRO_RAW_F16 consumers).  Channels below Cpart get their statistics from `part` (and store them in `stat`), the
-// others read `stat`.  g / b: per-segment stride gb_seg (0 = shared).
+// others read `stat`.  g / b: per-segment stride gb_seg (0 = shared).  yraw (may be null, same layout as y): f16(x) itself — the
+// operand of the block's 1x1 shortcut conv (reference src/stylettsdec.cpp:132-140,287-296 converts x to f16 in its im2col).
 hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, const double *part, int nblk, int Cpart, float eps,
                                float *stat, int stat_seg, const float *ga, const float *be, int gb_seg, float slope, void *y,
-                               int ldy, const Segs &segs);
+                               int ldy, const Segs &segs, void *yraw = nullptr);
 
 // ---- f32 linear layers: y[n][o] = dot(W[o][:], x[n][:]) + b[o] (ggml_mul_mat on f32 weights) --------
 // `extra` (may be null) is a second per-output addend applied after the bias: (acc + b[o]) + extra[o]

@@ -25,6 +25,8 @@ enum Knob : int
     ZV_CONV_MT,            // minimum tile height of the generic conv kernel
     ZV_CONV_NT,            // 1 / 2: output tiles per wave of the generic conv kernel
     ZV_CONV_SINGLE,        // 0: never the single-utterance MFMA loop, 2: also for one-chunk convs
+    ZV_CONV_GEMM,          // 0 never, 1 batches, 2 always: conv_gemm_kernel for wide convs over an f16 operand tensor
+    ZV_GEMM_ORDER,         // conv_gemm_kernel's workgroup order: 0 plain (group fastest), 1 one group per XCD, 2 the 9-tile group first
     ZV_CONV_LW,            // 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs
     ZV_PAIR_MT,            // 2 / 4: tile height of the pair kernels
     ZV_PAIR64_RING,        // 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring

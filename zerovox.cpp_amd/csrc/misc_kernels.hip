@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void norm_act_f16_kernel(const float *__restri
                                                            const double *__restrict__ part, int nblk, int Cpart, float eps,
                                                            float *__restrict__ stat, int stat_seg,
                                                            const float *__restrict__ ga, const float *__restrict__ be, int gb_seg,
-                                                           float slope, _Float16 *__restrict__ y, int ldy, const Segs segs)
+                                                           float slope, _Float16 *__restrict__ y, int ldy, _Float16 *__restrict__ yraw,
+                                                           const Segs segs)
 {
     __shared__ float sm[4][64];                  // mean, rstd, gamma, beta
     const int useg = blockIdx.y;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void norm_act_f16_kernel(const float *__restri
     const float4 g = *(const float4 *)&sm[2][c4], b = *(const float4 *)&sm[3][c4];
     const float *xs = x + (size_t)sg.row0 * ldx + c;
     _Float16 *ys = y + (size_t)sg.row0 * ldy + c;
+    _Float16 *yr = yraw ? yraw + (size_t)sg.row0 * ldy + c : nullptr;      // f16(x): the operand of a block's 1x1 shortcut conv
     typedef _Float16 half4v __attribute__((ext_vector_type(4)));
     for (int t0 = rl; t0 < L; t0 += 64)
     {
@@ -253,18 +255,27 @@ __global__ __launch_bounds__(256) void norm_act_f16_kernel(const float *__restri
             h[2] = (_Float16)(r.z > 0.f ? r.z : r.z * slope);
             h[3] = (_Float16)(r.w > 0.f ? r.w : r.w * slope);
             *(half4v *)(ys + (size_t)t * ldy) = h;
+            if (yr)
+            {
+                half4v hr;
+                hr[0] = (_Float16)v[u].x;
+                hr[1] = (_Float16)v[u].y;
+                hr[2] = (_Float16)v[u].z;
+                hr[3] = (_Float16)v[u].w;
+                *(half4v *)(yr + (size_t)t * ldy) = hr;
+            }
         }
     }
 }
 
 hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, const double *part, int nblk, int Cpart, float eps,
                                float *stat, int stat_seg, const float *ga, const float *be, int gb_seg, float slope, void *y,
-                               int ldy, const Segs &segs)
+                               int ldy, const Segs &segs, void *yraw)
 {
     if ((C & 3) || (ldx & 3) || (ldy & 3) || segs.nseg < 1 || Cpart > C) return hipErrorInvalidValue;
     if (Cpart > 0 && (segs.max_rows + 31) / 32 > nblk) return hipErrorInvalidValue;
     hipLaunchKernelGGL(norm_act_f16_kernel, dim3((C + 63) / 64, segs.nseg), dim3(256), 0, s, x, ldx, C, part, nblk, Cpart, eps, stat,
-                       stat_seg, ga, be, gb_seg, slope, (_Float16 *)y, ldy, segs);
+                       stat_seg, ga, be, gb_seg, slope, (_Float16 *)y, ldy, (_Float16 *)yraw, segs);
     return hipGetLastError();
 }
 

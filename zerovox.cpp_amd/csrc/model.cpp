@@ -44,7 +44,7 @@ float *Model::upload_vec(const GgufFile &g, const std::string &name, int expect_
 }
 
 // GGUF conv weight: ggml ne [K, IC, OC] f16 (k fastest), bias f32 [OC]  (SURVEY.md Appx A)
-ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin)
+ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin, bool gemm_pack)
 {
     const GgufTensor &w = g.get(wname);
     if (w.type != GGML_F16) fail(ZV_ERR_SHAPE, "tensor %s: conv weights must be f16", wname.c_str());
@@ -61,6 +61,14 @@ ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::s
     pack_conv_weight((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
     c.w = dev_alloc(packed.size() * 2 + 32768);      // slack: the MFMA loops request up to 16 KiB past the last block
     ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    if (gemm_pack && c.Cin_p >= 256 && conv_gemm_groups(c.Cout_p) >= 1)
+    {
+        // batches run the wide decoder convs on conv_gemm_kernel: the same weights once more, in its stream order
+        std::vector<uint16_t> p8(conv_gemm_weight_halfs(c.Cin_p, c.Cout_p, c.K));
+        pack_conv_weight_gemm((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, p8.data());
+        c.w8 = dev_alloc(p8.size() * 2);
+        ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
+    }
     if (!bname.empty())
     {
         const GgufTensor &b = g.get(bname);
@@ -297,15 +305,15 @@ Model::Model(const std::string &path, int dev) : device(dev)
             b.learned_sc = b.cin != b.cout;
             snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv1.w", i);
             snprintf(nb, sizeof(nb), "_mel_decoder.encode.%d.conv1.b", i);
-            b.conv1 = load_conv(g, nm, nb, b.cin);
+            b.conv1 = load_conv(g, nm, nb, b.cin, true);
             snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv2.w", i);
             snprintf(nb, sizeof(nb), "_mel_decoder.encode.%d.conv2.b", i);
-            b.conv2 = load_conv(g, nm, nb, b.cin);
+            b.conv2 = load_conv(g, nm, nb, b.cin, true);
             if (b.conv1.Cout != b.cin || b.conv2.Cout != b.cout) fail(ZV_ERR_SHAPE, "_mel_decoder.encode.%d: channel mismatch", i);
             if (b.learned_sc)
             {
                 snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.conv1x1.w", i);
-                b.sc = load_conv(g, nm, "", b.cin);
+                b.sc = load_conv(g, nm, "", b.cin, true);
             }
             snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm1.w", i); b.n1w = upload_vec(g, nm, b.cin);
             snprintf(nm, sizeof(nm), "_mel_decoder.encode.%d.norm1.b", i); b.n1b = upload_vec(g, nm, b.cin);
@@ -329,15 +337,15 @@ Model::Model(const std::string &path, int dev) : device(dev)
             b.learned_sc = b.cin != b.cout;
             snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv1.w", i);
             snprintf(nb, sizeof(nb), "_mel_decoder.decode.%d.conv1.b", i);
-            b.conv1 = load_conv(g, nm, nb, b.cin);
+            b.conv1 = load_conv(g, nm, nb, b.cin, true);
             snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv2.w", i);
             snprintf(nb, sizeof(nb), "_mel_decoder.decode.%d.conv2.b", i);
-            b.conv2 = load_conv(g, nm, nb, b.cout);
+            b.conv2 = load_conv(g, nm, nb, b.cout, true);
             if (b.conv1.Cout != b.cout || b.conv2.Cout != b.cout) fail(ZV_ERR_SHAPE, "_mel_decoder.decode.%d: channel mismatch", i);
             if (b.learned_sc)
             {
                 snprintf(nm, sizeof(nm), "_mel_decoder.decode.%d.conv1x1.w", i);
-                b.sc = load_conv(g, nm, "", b.cin);
+                b.sc = load_conv(g, nm, "", b.cin, true);
             }
             for (int k = 1; k <= 2; k++)
             {
@@ -621,7 +629,7 @@ size_t Model::arena_bytes_for(size_t n_rows, size_t t_rows, int nseg) const
     const size_t nblk = T / 32 + S;           // >= sum over segments of ceil(T_u / 32) ... sized per segment below
     (void)nblk;
     size_t dec = T * (CAT + 4 * 2 * Ed + 2 * dec_.R) * 4 + S * (size_t)(dec_.fc_out + 8 * CAT + 512) * 4 +
-                 3 * (T / 32 + S) * CAT * 16 + T * (CAT + 2 * Ed) * 2 + 65536;
+                 3 * (T / 32 + S) * CAT * 16 + T * (2 * CAT + 2 * Ed) * 2 + 65536;
     // encoder
     const size_t Fp = round_up(hp.conv_filter_size, 16);
     size_t enc = N * (Ed * 8 + 3 * Ed + Fp + 1024) * 4 + 65536;
@@ -733,6 +741,7 @@ ConvJob Model::job(const ConvW &w) const
     j.pad = (w.K - 1) / 2;
     j.ck = w.ck;
     j.w = w.w;
+    j.w8 = w.w8;
     j.bias = w.bias;
     j.pro = PRO_ACT;
     j.slope = 1.0f;
@@ -1191,7 +1200,7 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     float *x0 = arena_.take_n<float>(L * B);
     float *xa = arena_.take_n<float>(L * B);
     float *asr_t = arena_.take_n<float>(L * R);
-    _Float16 *xa16 = arena_.take_n<_Float16>(L * CAT), *t16 = arena_.take_n<_Float16>(L * B);
+    _Float16 *xa16 = arena_.take_n<_Float16>(L * CAT), *t16 = arena_.take_n<_Float16>(L * B), *xr16 = arena_.take_n<_Float16>(L * CAT);
     const double Ld = (double)L;
     // Two ways to feed a conv its normalised operand, same bits (tests): (a) the conv normalises while it stages its
     // input tile (PRO_NORM_ACT) — no extra launch, right for a single utterance where every launch is latency; (b) one
@@ -1213,11 +1222,11 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     };
     // make `j` read lrelu(norm(x)) with x's statistics still in `part` (channels [0, Cpart)); stores them in `stat`
     auto norm_input = [&](ConvJob &j, const float *x, int ldx, int C, const double *part, int Cpart, float *stat, const float *g,
-                          const float *b, int gb_seg, _Float16 *op16) {
+                          const float *b, int gb_seg, _Float16 *op16, _Float16 *raw16 = nullptr) {
         if (prepass)
         {
             ZV_LAUNCH("dec_norm_operand", 6.0 * Ld * C, 8.0 * Ld * C,
-                      launch_norm_act_f16(stream, x, ldx, C, part, nblk, Cpart, 1e-5f, stat, ss, g, b, gb_seg, 0.2f, op16, C, fr));
+                      launch_norm_act_f16(stream, x, ldx, C, part, nblk, Cpart, 1e-5f, stat, ss, g, b, gb_seg, 0.2f, op16, C, fr, raw16));
             j.x0 = op16;
             j.ldx = C;
             j.pro = PRO_RAW_F16;
@@ -1262,7 +1271,8 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         int nj = 0;
         {
             ConvJob j = job(b.conv1);
-            norm_input(j, x, ldx, b.cin, part_o, Cpart, st_in, g1, b1, gb_seg, xa16);
+            // (a learned shortcut reads f16(x): with the pre-pass on, that operand is written by the same pass)
+            norm_input(j, x, ldx, b.cin, part_o, Cpart, st_in, g1, b1, gb_seg, xa16, b.learned_sc ? xr16 : nullptr);
             j.out = t1;
             j.stat_part = part_t;
             j.stat_nblk = nblk;
@@ -1275,6 +1285,12 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
             ConvJob j = job(b.sc);
             j.x0 = x;
             j.ldx = ldx;
+            if (prepass)
+            {
+                j.x0 = xr16;
+                j.ldx = b.cin;
+                j.pro = PRO_RAW_F16;
+            }
             j.out = sc;
             res = sc;
             ldres = b.sc.Cout_p;

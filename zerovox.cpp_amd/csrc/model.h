@@ -21,6 +21,7 @@ namespace zv
 struct ConvW
 {
     void  *w = nullptr;
+    void  *w8 = nullptr;        // conv_gemm_kernel's stream order (wide decoder convs), or null
     float *bias = nullptr;
     int    K = 0, Cin = 0, Cout = 0, Cin_p = 0, Cout_p = 0, ck = 0;
 };
@@ -184,7 +185,7 @@ class Model
     void  *dev_alloc(size_t bytes);
     float *upload_f32(const GgufTensor &t, int pad_to = 0, float pad_value = 0.f);
     float *upload_vec(const GgufFile &g, const std::string &name, int expect_n, int pad_to = 0, float pad_value = 0.f);
-    ConvW  load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin = -1);
+    ConvW  load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin = -1, bool gemm_pack = false);
     ConvW  load_upsample(const GgufFile &g, int idx, int stride, int expect_cin);
 
     struct ResPair { ConvW c1, c2; void *p1 = nullptr, *p2 = nullptr, *r1 = nullptr, *r2 = nullptr; };   // p1/p2: fused-kernel weight layout, r1/r2: LDS-ring layout (64 channels)
