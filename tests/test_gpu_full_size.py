@@ -226,6 +226,9 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
     for name, env in (("default", {}), ("fuse256", {"ZV_FUSE256": "1"}), ("no_triple", {"ZV_NO_TRIPLE": "1"}), ("no_fuse", {"ZV_NO_FUSE": "1"}),
                       ("no_merge", {"ZV_NO_MERGE": "1"}), ("fuse256_no_merge", {"ZV_FUSE256": "1", "ZV_NO_MERGE": "1"}),
                       ("merge", {"ZV_MERGE_ALWAYS": "1"}), ("fuse256_merge", {"ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1"}),
+                      ("merge_in_one_workgroup", {"ZV_MERGE_ALWAYS": "1", "ZV_MERGE_SEQ": "0"}),
+                      ("fuse256_merge_in_one_workgroup", {"ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1", "ZV_MERGE_SEQ": "0"}),
+                      ("fuse256_merge_mt3", {"ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1", "ZV_PAIR_MT": "3"}),
                       ("pair64_ring_merge", {"ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1"}),
                       ("single_loop_everywhere", {"ZV_CONV_SINGLE": "2"}), ("no_single_loop", {"ZV_CONV_SINGLE": "0"}),
                       ("loader_waves", {"ZV_CONV_LW": "2"}),

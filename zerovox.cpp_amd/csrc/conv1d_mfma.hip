@@ -1307,7 +1307,10 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     if (P.dbg & 4) return;
     const int nrows = (L - t0 < TM) ? (L - t0) : TM;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    float *const outp = (!MERGE && P.sum_out) ? P.sum_out + (size_t)sg.row0 * jobs.rate * CP : out_seg;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(outp + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sum = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((P.sum_in ? P.sum_in : y_seg) + (P.sum_in ? (size_t)sg.row0 * jobs.rate * CP : 0) + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
     {
@@ -1335,6 +1338,22 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
                     for (int r = 0; r < 16; r++)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(msum[mt][nt][r]), rs_out, voff,
                                                               (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
+            }
+            else if (P.sum_out)
+            {
+                // this branch's term of the MRF sum: sum_out = sum_in + v (the first branch stores v itself)
+                float sumv[16];
+                if (P.sum_in)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        sumv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sum, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const float v = (acc[mt][nt][r] + bias) + resv[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(P.sum_in ? sumv[r] + v : v), rs_out, voff,
+                                                          (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
+                }
             }
             else
             {
@@ -2456,8 +2475,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
 
     // descriptors: the utterance's rows of the operand tensor (anything outside reads as zero = the conv's zero padding) and
     // this group's weight stream (groups before the last one have 8 tiles)
-    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (unsigned)((size_t)L * ldx * 2));
-    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (unsigned)((size_t)nunits * bunit));
+    // (J.dbg, timing ablations only: bit 1 / bit 2 = the operand / weight descriptor covers nothing, every piece arrives as zeros
+    // without touching memory)
+    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (J.dbg & 1) ? 0u : (unsigned)((size_t)L * ldx * 2));
+    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (J.dbg & 2) ? 0u : (unsigned)((size_t)nunits * bunit));
 
     // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
     // slot); the slot holds the 16-byte piece (slot ^ ((row >> 2) & 3)) of the row's 64 bytes
@@ -2671,7 +2692,8 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
 {
     ConvJobs js;
     js.j[0] = job;
-    for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = job;
+    js.j[0].dbg = knob(ZV_DBG);
+    for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     js.segs = segs;
     js.rate = rate;
     js.nt_begin = knob(ZV_GEMM_ORDER);

@@ -157,6 +157,10 @@ struct PairJob
     int          L, Cp, K, dil;
     float        slope;
     int          dbg;
+    // the running MRF sum, branch by branch (reference src/hifigan.cpp:300-315: (y0 + y1) + y2): when sum_out is set the pair's
+    // result v goes there instead of `out`, as sum_in + v (or v itself for the first branch, sum_in null); may be the same buffer
+    const float *sum_in;
+    float       *sum_out;
 };
 constexpr int PAIR_MAX_JOBS = 3;
 struct PairJobs

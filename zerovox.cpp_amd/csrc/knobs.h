@@ -16,6 +16,7 @@ enum Knob : int
     ZV_FUSE256,            // 1: fused pair kernel for the 256-channel stage at any length
     ZV_NO_MERGE,           // 1: three branch outputs instead of their sum
     ZV_MERGE_ALWAYS,       // 1: the merged MRF sum at any length (default: only with rounds of workgroups to spare)
+    ZV_MERGE_SEQ,          // 0: the wide stages' MRF sum by one three-branch workgroup per tile instead of three single-branch launches
     ZV_MERGE_MAXC,         // widest stage whose last dilation pair stores the merged sum (batches)
     ZV_VOC_GROUP,          // G > 0: the vocoder runs G utterances at a time (experiment)
     ZV_TAIL_GROUPS,        // utterance groups of a batch's last vocoder stage (default 4)

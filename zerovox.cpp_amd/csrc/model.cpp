@@ -1035,7 +1035,22 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             {
                 float *ms = (pj[0].out != pj[0].y && pj[0].out != pj[1].y && pj[0].out != pj[2].y) ? pj[0].out : nullptr;
                 if (!ms) fail(ZV_ERR_DEVICE, "internal: no free buffer for the merged MRF sum");
-                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate, ms));
+                if (Cp >= 256 && knob(ZV_MERGE_SEQ) != 0)
+                {
+                    // 256 channels: the branches one launch each on the side-by-side kernel (96-row tiles, all staging loads in flight:
+                    // 1 020 us for the three against 1 105 us for the three-branches-per-workgroup form; at 128 channels the single-
+                    // branch launches' tails cost more than they gain: 1 422 against 1 386 us), every launch adding its term into the
+                    // running sum — (y0 + y1) + y2, the merged form's association, hence its bits
+                    for (int jb = 0; jb < 3; jb++)
+                    {
+                        PairJob q = pj[jb];
+                        q.sum_out = ms;
+                        q.sum_in = jb ? ms : nullptr;
+                        ZV_LAUNCH("voc_resblock_conv", (b1 + b2) / 3, (f1 + f2) / 3, launch_pair(stream, &q, 1, n_cu, fr, rate));
+                    }
+                }
+                else
+                    ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate, ms));
                 merged_sum = ms;
             }
             else if (fused)
