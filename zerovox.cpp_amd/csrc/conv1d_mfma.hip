@@ -2516,12 +2516,19 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
     };
     // per half and wave: two operand pieces, two weight fragments (+ one more for waves 0 and 1 where a ninth tile rides along:
     // 18 fragments); the same count in every half, so the counted waits below hold
+    const bool no_dma = (J.dbg & 4) != 0;          // timing ablation: no piece is requested at all (the loop runs on stale LDS)
+    auto issue_pa = [&](int i) {
+        if (!no_dma) dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff));
+    };
+    auto issue_pb = [&](int i) {
+        if (!no_dma) dma_piece(rs_b, i_abase + AH + (wave * 2 + i) * 1024, (unsigned)(i_boff + (wave * 2 + i) * 1024 + lane * 16));
+    };
     auto issue_part = [&](int i) {
-        dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff));
-        dma_piece(rs_b, i_abase + AH + (wave * 2 + i) * 1024, (unsigned)(i_boff + (wave * 2 + i) * 1024 + lane * 16));
+        issue_pa(i);
+        issue_pb(i);
     };
     auto issue_x = [&]() {
-        if (EXTRA && wave < 2) dma_piece(rs_b, i_abase + AH + (16 + wave) * 1024, (unsigned)(i_boff + (16 + wave) * 1024 + lane * 16));
+        if (EXTRA && wave < 2 && !no_dma) dma_piece(rs_b, i_abase + AH + (16 + wave) * 1024, (unsigned)(i_boff + (16 + wave) * 1024 + lane * 16));
     };
     const bool five = EXTRA && wave < 2;             // this wave requests five pieces per half
 
@@ -2542,6 +2549,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
     floatx16 accx;
 #pragma unroll
     for (int r = 0; r < 16; r++) accx[r] = 0.f;
+    // waves 4-7 (the second-dispatched half of the workgroup) lose the issue arbitration to their SIMD partners 0-3 on every
+    // segment (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for them
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     // prologue: halves 0, 1, 2 requested
 #pragma unroll
     for (int h = 0; h < 3; h++)
@@ -2552,17 +2562,29 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
             issue_part(1);
             issue_x();
         }
-    for (int h = 0; h < nhalf; h++)
+#ifdef ZV_STAMPS
+    // diagnostic build: wave 0 splits its loop time into (counted wait, barrier, the rest) and stores the sums
+    unsigned long long st_wait = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_loop0 = st_t0;
+#endif
+    // step-0 fragments of the half about to be consumed: read from LDS at the END of the previous iteration (that half has
+    // landed for every wave one barrier earlier: the counted wait below asks for half h + 1, not h), so the MFMAs start right
+    // behind the barrier instead of an LDS round trip later (the two waves of a SIMD stand at the barrier together: nothing
+    // else would fill that gap — 250 of a half unit's 1 900 cycles)
+    half8 a0[4], b0[2], ax0, bx0;
+#define ZV_G_READ0(hn)                                                                                            \
+    {                                                                                                             \
+        const char *nb_ = smem + ((hn) & 3) * SLOT;                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < 4; mt++) a0[mt] = *(const half8 *)(nb_ + a_rd[0] + mt * 2048);    \
+        _Pragma("unroll") for (int nt = 0; nt < 2; nt++) b0[nt] = *(const half8 *)(nb_ + b_rd + nt * 1024);       \
+        if constexpr (EXTRA)                                                                                      \
+        {                                                                                                         \
+            ax0 = *(const half8 *)(nb_ + ax_rd[0]);                                                               \
+            bx0 = *(const half8 *)(nb_ + AH + 8 * 1024 + lane * 16);                                              \
+        }                                                                                                         \
+    }
     {
-        // half h has landed for this wave once at most the pieces of h + 1 and h + 2 are outstanding; after the barrier it has
-        // for every wave, and every wave is done reading slot (h - 1) & 3 = (h + 3) & 3: half h + 3 can go there
-        const int ahead = min(2, nhalf - 1 - h);     // halves requested beyond h
-        if (ahead == 2)
-        {
-            if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        else if (ahead == 1)
+        // half 0 (and 1) landed and visible before the loop starts
+        if (nhalf > 2)
         {
             if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -2570,41 +2592,100 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        ZV_G_READ0(0)
+    }
+    for (int h = 0; h < nhalf; h++)
+    {
+#ifdef ZV_STAMPS
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
+        // before the barrier: half h + 1 has landed for this wave (at most the pieces of h + 2 outstanding); after it, for every
+        // wave, and every wave is done reading slot (h - 1) & 3 = (h + 3) & 3: half h + 3 can go there
+        if (h > 0)
+        {
+            if (h + 2 < nhalf)
+            {
+                if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ZV_STAMPS
+            const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();
+#ifdef ZV_STAMPS
+            const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+            st_wait += st_b - st_a;
+            st_bar += st_c - st_b;
+#endif
+        }
         const bool more = h + 3 < nhalf;
         if (more) issue_begin(h + 3);
         const char *buf = smem + (h & 3) * SLOT;
-        half8 a[2][4], b[2][2], ax[2], bx[2];
+        half8 a1[4], b1[2], ax1, bx1;
 #pragma unroll
-        for (int st = 0; st < 2; st++)
+        for (int mt = 0; mt < 4; mt++) a1[mt] = *(const half8 *)(buf + a_rd[1] + mt * 2048);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) b1[nt] = *(const half8 *)(buf + b_rd + b_st + nt * 1024);
+        if constexpr (EXTRA)
         {
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) a[st][mt] = *(const half8 *)(buf + a_rd[st] + mt * 2048);
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) b[st][nt] = *(const half8 *)(buf + b_rd + st * b_st + nt * 1024);
-            if constexpr (EXTRA)
-            {
-                ax[st] = *(const half8 *)(buf + ax_rd[st]);
-                bx[st] = *(const half8 *)(buf + AH + st * b_st + 8 * 1024 + lane * 16);
-            }
+            ax1 = *(const half8 *)(buf + ax_rd[1]);
+            bx1 = *(const half8 *)(buf + AH + b_st + 8 * 1024 + lane * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // four groups of four MFMAs (one output-tile column of one k16 step), one piece requested behind each
+#define ZV_G_COL(av, bv, nt, ZERO)                                                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < 4; mt++)                                                                     \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[mt], bv[nt], (ZERO) ? zero16 : acc[mt][nt], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0);
+        const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (h == 0)
-            mfma_step<4, 2, false, true>(acc, a[0], b[0]);
+        {
+            ZV_G_COL(a0, b0, 0, true)
+            if (more) issue_pa(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G_COL(a0, b0, 1, true)
+        }
         else
-            mfma_step<4, 2, false>(acc, a[0], b[0]);
-        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[0], bx[0], accx, 0, 0, 0);
+        {
+            ZV_G_COL(a0, b0, 0, false)
+            if (more) issue_pa(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G_COL(a0, b0, 1, false)
+        }
+        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax0, bx0, accx, 0, 0, 0);
+        if (more) issue_pb(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) issue_part(0);
+        // the next half's first fragments (visible since this iteration's barrier), under the last eight MFMAs
+        if (h + 1 < nhalf) ZV_G_READ0(h + 1)
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step<4, 2, false>(acc, a[1], b[1]);
-        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[1], bx[1], accx, 0, 0, 0);
+        ZV_G_COL(a1, b1, 0, false)
+        if (more) issue_pa(1);
         __builtin_amdgcn_sched_barrier(0);
+        ZV_G_COL(a1, b1, 1, false)
+        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax1, bx1, accx, 0, 0, 0);
         if (more)
         {
-            issue_part(1);
+            issue_pb(1);
             issue_x();
         }
+#undef ZV_G_COL
     }
+#undef ZV_G_READ0
+#ifdef ZV_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096)
+    {
+        const unsigned long long st_e = __builtin_amdgcn_s_memtime();
+        unsigned long long *sb = zv_stamp_buf + (size_t)blockIdx.x * ZV_STAMP_N;
+        sb[0] = st_e - st_loop0;      // loop cycles
+        sb[1] = st_wait;              // in the counted vmcnt waits
+        sb[2] = st_bar;               // in the barriers
+        sb[3] = nhalf;
+        sb[4] = EXTRA;
+        sb[7] = 1;
+    }
+#endif
     constexpr bool extra = EXTRA;
 
     // ---- epilogue: bias, residual, scale, activation, f32 store, InstanceNorm partial sums (as conv1d_mfma_kernel) ----
