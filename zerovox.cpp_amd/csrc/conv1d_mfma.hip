@@ -734,7 +734,6 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
         {
             const int c0 = ic * J.ck;
             const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-            char *cur = smem + (ic & 1) * tile_bytes;
             if (is_loader)
             {
                 if (ic + 1 < nchunk && !(J.dbg & 1))
@@ -758,7 +757,6 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
                 else
                     mfma_chunk<MT, NT>(acc, ab, RS, dil, wp, wseg, K, ck >> 4);
             }
-            (void)cur;
             // the next chunk's tile is complete and this chunk's tile is free again
             if (ic + 1 < nchunk) __syncthreads();
         }
@@ -958,6 +956,7 @@ static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs
     js.rate = rate;
     js.tps = 0;
     js.nt_begin = nt_begin;
+    js.order = 0;
     const int Lmax = segs.max_rows * rate;
     int halo = 0, ck = 0, dmax = 1;
     for (int i = 0; i < njobs; i++)
@@ -2367,7 +2366,7 @@ int conv_gemm_tiles(int Cout_p)
     return ng * 8 + ((nt - ng * 8 == 1 && ng >= 1) ? 1 : 0);
 }
 
-__device__ __forceinline__ int Cout_p_groups(int Cout_p) { return ((Cout_p + 31) >> 5) >> 3; }
+__device__ __forceinline__ int gemm_groups_dev(int Cout_p) { return ((Cout_p + 31) >> 5) >> 3; }
 
 __device__ __forceinline__ int conv_gemm_units_dev(int Cin_p, int K)
 {
@@ -2456,7 +2455,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
     constexpr int AH = 16384, BH = ntg * 2048;       // bytes of a half unit's operand slice / weight fragments
     constexpr int SLOT = AH + 18432;                 // one ring slot (room for 9 tiles)
     const ConvJob &J = jobs.j[0];
-    const int ng = (Cout_p_groups(J.Cout_p));
+    const int ng = (gemm_groups_dev(J.Cout_p));
     const int useg = rt / jobs.tps;
     const Seg sg = seg_at(jobs.segs, useg);
     const int L = sg.rows * jobs.rate;
@@ -2735,21 +2734,18 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvJobs jobs)
 {
     const ConvJob &J = jobs.j[0];
-    // workgroup -> (group of 8 output tiles, row tile), XCD-aware: workgroups are dealt round-robin over the 8 XCDs (observed, only
-    // the speed depends on it), each with its own 4-MiB L2.  A group's weight stream is 1.7 MB for a 1 056-channel conv, all four
-    // groups' 6.7 MB: an XCD that works on ONE group keeps its weights in L2, one that works on all of them fetches every block
-    // from the Infinity Cache (measured: 2.2 us per unit = 29 GB/s per CU, that cache's rate, against 1.1 us of MFMAs).
-    const int ng = (Cout_p_groups(J.Cout_p));
+    // workgroup -> (group of 8 output tiles, row tile)
+    const int ng = (gemm_groups_dev(J.Cout_p));
     const int rts = jobs.tps * jobs.segs.nseg;
     int g, rt;
-    if (jobs.nt_begin == 1 && (ng == 1 || ng == 2 || ng == 4))        // (nt_begin carries the order in this kernel: A/B hook)
+    if (jobs.order == 1 && (ng == 1 || ng == 2 || ng == 4))
     {
         // XCD-aware: one group per XCD (its weight stream stays in that L2).  Measured: no faster than the plain order.
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / ng;
         g = xcd % ng;
         rt = idx * per + xcd / ng;
     }
-    else if (jobs.nt_begin == 2 && ng > 1)
+    else if (jobs.order == 2 && ng > 1)
     {
         // longest jobs first: the last group may carry a ninth tile (+ 12 % work); dispatched first, its workgroups are paired
         // with 8-tile ones on their CUs by the dispatcher (two workgroups per CU and launch: 9 + 8 instead of 9 + 9)
@@ -2777,13 +2773,14 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
     for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     js.segs = segs;
     js.rate = rate;
-    js.nt_begin = knob(ZV_GEMM_ORDER);
+    js.nt_begin = 0;
+    js.order = knob(ZV_GEMM_ORDER);
     const int Lmax = segs.max_rows * rate;
     js.tps = (Lmax + 255) / 256;
     if (job.stat_part && job.stat_nblk * 32 < Lmax) return hipErrorInvalidValue;
     const int ng = conv_gemm_groups(job.Cout_p), rts = js.tps * segs.nseg;
     // (grid.x covers (row tile, group) in the kernel's XCD-aware order: 8 / ng XCDs per group)
-    const dim3 grid((js.nt_begin == 1 && (ng == 1 || ng == 2 || ng == 4)) ? round_up(rts, 8 / ng) * ng : rts * ng, 1, 1);
+    const dim3 grid((js.order == 1 && (ng == 1 || ng == 2 || ng == 4)) ? round_up(rts, 8 / ng) * ng : rts * ng, 1, 1);
     const int lds = 4 * (16384 + 18432);
     static bool attr_set = false;
     if (!attr_set)

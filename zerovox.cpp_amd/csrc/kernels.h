@@ -121,6 +121,7 @@ struct ConvJobs
     int     rate;                // rows per base row of this launch
     int     tps;                 // row tiles per segment (grid.x = tps * nseg)
     int     nt_begin;            // first output tile of this launch (the tiles before it belong to conv_gemm_kernel)
+    int     order;               // conv_gemm_kernel: workgroup order (ZV_GEMM_ORDER: 0 plain, 1 one group per XCD, 2 the 9-tile group first)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
