@@ -41,6 +41,12 @@ static constexpr int CK_MAX = 256;
 // 16-byte pieces a thread keeps in flight while it stages a tile (10 — one round trip for every small tile — measured no
 // faster on the batch's upsample convs and costs the MT = 1 kernels a wave of occupancy)
 #ifndef ZV_STAGE_U
+// timing-only ablation build (-DZV_ABL_A): only the first row tile's A fragment is read from LDS, the others copy it
+#ifdef ZV_ABL_A
+#define ZV_ABL_LD(arr, p, mt) ((mt) == 0 ? *(const half8 *)(p) : arr[0])
+#else
+#define ZV_ABL_LD(arr, p, mt) (*(const half8 *)((p) + (mt) * 32 * RS))
+#endif
 #define ZV_STAGE_U 4
 #endif
 #ifndef ZV_STAGE_U128
@@ -488,7 +494,7 @@ __device__ __forceinline__ void mfma_taps_deep(floatx16 (&acc)[MT][NT], const ch
 #define ZV_LOAD_A2(un)                                                                        \
     {                                                                                         \
         const char *np_ = ZV_A_ADDR2(un);                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 8][mt] = *(const half8 *)(np_ + mt * 32 * RS); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[(un) % 8][mt] = ZV_ABL_LD(a[(un) % 8], np_, mt); \
     }
 #define ZV_STEP2(u, bset) ZV_LOAD_A2((u) + DEPTH) mfma_step<MT, NT, SWAP>(acc, a[(u) % 8], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
 #define ZV_STEP2Z(u, bset) ZV_LOAD_A2((u) + DEPTH) mfma_step<MT, NT, SWAP, true>(acc, a[(u) % 8], bset[(u) % 4]); __builtin_amdgcn_sched_barrier(0);
@@ -990,12 +996,15 @@ static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs
         // element against 8 bytes moved) want workgroups in flight, not weight reuse: measured on the batch, the last
         // three upsample convs take 897 / 595 / 452 us with the tall tiles and 636 / 569 / 416 us with these
         const double ai = 2.0 * jobs[0].K * jobs[0].Cin_p * Cout_p / (4.0 * (jobs[0].Cin_p + Cout_p));
-        if (ai < 200.0 && wgs(1, 1) >= 16L * n_cu) MT = std::min(MT, Cout_p <= 128 ? 2 : 1);
+        // (round 3: 64-row tiles for all of them — the 128 -> 4 x 64 channel one 573 -> 501 us: half the weight stream per row)
+        if (ai < 200.0 && wgs(1, 1) >= 16L * n_cu) MT = std::min(MT, 2);
     }
     if (MT < knob(ZV_CONV_MT)) MT = knob(ZV_CONV_MT);      // measurement hook: minimum MT
     // two output tiles per wave once a conv is wide and the launch still has rounds of workgroups to spare
     const int nt_env = knob(ZV_CONV_NT);
-    int NT = (WN == 4 && ntiles >= 8 && MT >= 2 && wgs(MT, 2) >= 4L * n_cu) ? 2 : 1;
+    // ... and deep (>= 2 048 products per output element: the decoder's; the first two upsample convs, 1 536 / 768 deep, measured
+    // 265 / 417 us on 64 x 64 wave tiles and 245 / 395 us on 128 x 32 ones)
+    int NT = (WN == 4 && ntiles >= 8 && MT >= 2 && wgs(MT, 2) >= 4L * n_cu && jobs[0].K * jobs[0].Cin_p >= 2048) ? 2 : 1;
     if (nt_env == 1 || (nt_env == 2 && WN == 4 && ntiles >= 2 && MT >= 2)) NT = nt_env;
     if (NT == 2 && MT == 4) MT = 2;        // 64 x 64 per wave: the 128 x 64 shape does not fit 256 registers
     {
@@ -1178,12 +1187,17 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     constexpr int WN = CP / 32 / NT, WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[blockIdx.z].K - 1);
+    // `interleave` jobs share their input (a block's first dilation pair): the branches of one stretch of the sequence run next
+    // to each other on the same XCD (blockIdx.x & 7 picks the XCD) on one common tiling, so only the first fetches it from HBM
+    const int il = MERGE ? 1 : jobs.interleave;
+    const int jz = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
+    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int TM = BM - ((MERGE || il > 1) ? jobs.kmax - 1 : jobs.j[jz].K - 1);
     // workgroup -> (segment, time tile): every segment gets the tile count of the longest one, tiles past a segment's
     // end exit; the XCD map runs over the whole (segment, tile) range, so an XCD works on neighbouring tiles of
     // neighbouring utterances
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
     if (vt >= tps * jobs.segs.nseg) return;
     const int useg = vt / tps;
     const Seg sg = seg_at(jobs.segs, useg);
@@ -1191,7 +1205,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
 #ifdef ZV_STAMPS
-    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.z;
+    const int stamp_wg = il > 1 ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * blockIdx.z);
     if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
     {
         zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
@@ -1201,7 +1215,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 #endif
     ZV_STAMP(0)
     floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
-    for (int jb = MERGE ? 0 : (int)blockIdx.z; jb < (MERGE ? jobs.njobs : (int)blockIdx.z + 1); jb++)
+    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
     {
     const PairJob &P = jobs.j[jb];
     const int K = P.K, dil = P.dil;
@@ -1415,9 +1429,14 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 {
     constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
     constexpr int CHUNK = 8 * 1024;                  // one tap: 4 channel steps x 2 output tiles
-    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[blockIdx.z].K - 1);
+    // `interleave` jobs share their input (a block's first dilation pair): the branches of one stretch of the sequence run next
+    // to each other on the same XCD (blockIdx.x & 7 picks the XCD) on one common tiling, so only the first fetches it from HBM
+    const int il = MERGE ? 1 : jobs.interleave;
+    const int jz = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
+    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int TM = BM - ((MERGE || il > 1) ? jobs.kmax - 1 : jobs.j[jz].K - 1);
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
     if (vt >= tps * jobs.segs.nseg) return;
     const int useg = vt / tps;
     const Seg sg = seg_at(jobs.segs, useg);
@@ -1426,7 +1445,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     if (t0 >= L) return;
 
 #ifdef ZV_STAMPS
-    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.z;
+    const int stamp_wg = il > 1 ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * blockIdx.z);
     if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
     {
         zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
@@ -1443,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     const char *bl = ring + lane * 16;
 
     floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
-    for (int jb = MERGE ? 0 : (int)blockIdx.z; jb < (MERGE ? jobs.njobs : (int)blockIdx.z + 1); jb++)
+    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
     {
         const PairJob &P = jobs.j[jb];
         const int K = P.K, dil = P.dil;
@@ -1499,7 +1518,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 #define ZV_LDR(slot, aptr, boff)                                                                                      \
     {                                                                                                                 \
         const char *ap_ = (aptr);                                                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = ZV_ABL_LD(a[slot], ap_, mt);                  \
         _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[slot][nt] = *(const half8 *)(bp_ + (boff) + nt * 1024);  \
     }
 #define ZV_MF(slot, SW, Z)                                \
@@ -1675,6 +1694,7 @@ static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int
     constexpr int BM = 256;
     const int TMmin = BM - (Kmax - 1);
     dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);
+    if (!MERGE && js.interleave > 1) grid = dim3(grid.x * njobs, 1, 1);
     // operand rows: BM + (K - 1) * dil, + dil: the last tap's prefetch reads one tap past the end
     js.ring_off = round_up((BM + Kmax * dmax) * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
@@ -1703,6 +1723,7 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
     dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);      // multiple of 8: zv_xcd_tile
+    if (!MERGE && js.interleave > 1) grid = dim3(grid.x * njobs, 1, 1);
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil.  The loop walks
     // whole taps once a tap is at least a body (CP >= 128): K + 1 taps (51 KB for the 128-channel stage: room for three
     // workgroups per CU instead of two — measured worth 0.6 %)
@@ -1733,15 +1754,20 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
 #endif
     const int Lmax = segs.max_rows * rate;
     int Kmax = 0, dmax = 0;
+    bool same_in = njobs > 1 && !merge_out;
     for (int i = 0; i < njobs; i++)
     {
         js.j[i] = jobs[i];
         js.j[i].dbg = dbg;
+        same_in = same_in && jobs[i].y == jobs[0].y;
         if (jobs[i].Cp != jobs[0].Cp) return hipErrorInvalidValue;
         Kmax = jobs[i].K > Kmax ? jobs[i].K : Kmax;
         dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
     }
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
+    // batches whose jobs read the same tensor: branches interleaved per XCD (ZV_PAIR_INTERLEAVE = 0 never, 2 at any length)
+    const int il_env = knob(ZV_PAIR_INTERLEAVE);
+    js.interleave = (same_in && il_env && (il_env == 2 || (long)Lmax * segs.nseg >= 2048L * n_cu)) ? njobs : 1;
     const int Cp = jobs[0].Cp;
     const int WN = Cp == 256 ? 4 : Cp / 32;
     auto wgs = [&](int MT) {
@@ -1984,7 +2010,7 @@ __device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *
 #define ZV_LD(slot, aptr, woff)                                                                                       \
     {                                                                                                                 \
         const char *ap_ = (aptr);                                                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = ZV_ABL_LD(a[slot], ap_, mt);                  \
         b[slot][0] = *(const half8 *)(wl + (woff));                                                                   \
     }
 #define ZV_ST(slot, Z)                                   \
@@ -2046,21 +2072,29 @@ __device__ __forceinline__ void pack_all(unsigned pa, const uint2 (&pk)[MT_][4])
     if constexpr (I + 1 < MT_ * 4) pack_all<MT_, I + 1>(pa, pk);
 }
 
-template <int MT, int R>
+template <int MT, int R, bool SUM>
 __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32_kernel(const TripleJobs jobs)
 {
     constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     // workgroup -> (job, tile): with `il` jobs interleaved the MRF branches of one stretch of the sequence run next to each
-    // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM
-    const int il = jobs.interleave;
+    // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM.
+    // jobs.sum_out: ONE workgroup runs every job of its tile, one after the other on one common tiling, and only the running
+    // sum (out_0 + out_1) + out_2 exists in memory: job j > 0 reads the sum back (from L2: this workgroup stored it a block
+    // earlier), adds its own output and stores it again — the output conv then reads one tensor instead of three.
+    constexpr bool sum_mode = SUM;
+    const int il = sum_mode ? 1 : jobs.interleave;
     const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const TripleJob &P = jobs.j[il > 1 ? (blockIdx.x >> 3) % il : blockIdx.z];
-    const int K = P.K, nd = P.n_dil;
-    const int h2 = (K - 1) / 2;
-    int sumd = 0, dmax = 1;
-    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
-    const int H = h2 * (sumd + nd);
+    const int j_first = sum_mode ? 0 : (il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z);
+    const int j_end = sum_mode ? jobs.njobs : j_first + 1;
+    // the tiling: the job's own halo, or in sum mode the widest halo of the jobs (jobs.hmax) for all of them
+    int H;
+    {
+        const TripleJob &P0 = jobs.j[j_first];
+        int sumd0 = 0;
+        for (int d = 0; d < P0.n_dil; d++) sumd0 += P0.dil[d];
+        H = sum_mode ? jobs.hmax : ((P0.K - 1) / 2) * (sumd0 + P0.n_dil);
+    }
     const int TM = R - 2 * H;
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
     const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
@@ -2070,10 +2104,28 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
     const int L = sg.rows * jobs.rate;
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
-    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
-    const int XM = h2 * dmax;
     const bool edge = t0 - H < 0 || t0 - H + R > L;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31;
+    const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x;
+    int stamp_k = 1;
+#endif
+    ZV_STAMP(0)
+
+    for (int jb = j_first; jb < j_end; jb++)
+    {
+    const TripleJob &P = jobs.j[jb];
+    const int K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int dmax = 1;
+    for (int d = 0; d < nd; d++) dmax = P.dil[d] > dmax ? P.dil[d] : dmax;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    const int XM = h2 * dmax;
     const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
     const int nb = ((K * NKC + 3) >> 2) >> 1;         // 8-step bodies per conv
     const int nblk = 8 * nb;                          // weight fragments per conv (real ones first, zero blocks behind)
@@ -2084,22 +2136,16 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
     // that form show 2 us of DMA latency in each of a block's six pack / epilogue phases (27.6 us per workgroup).
     // The biases of the block's six convs sit in LDS, so nothing in the loop below waits on the vector-memory counter but
     // the barriers that are meant to.
-    const bool db = (jobs.db_mask >> (il > 1 ? (blockIdx.x >> 3) % il : blockIdx.z)) & 1;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const bool db = (jobs.db_mask >> jb) & 1;
     char *wlds = smem + round_up(xrows * RS, 1024);
     char *wlds2 = db ? wlds + nblk * 1024 : wlds;                  // conv2's weights
     float *blds = (float *)(wlds + (db ? 2 : 1) * nblk * 1024 + 2048);      // behind the last-prefetch slack: [d][conv][32]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31;
-    const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
-
-#ifdef ZV_STAMPS
-    const int stamp_wg = blockIdx.x;
-    int stamp_k = 1;
-#endif
-    ZV_STAMP(0)
+    if (jb > j_first)
+    {
+        // the previous job's last conv2 is done reading the operand region and its weights
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
     if (tid < 64 * nd)
     {
@@ -2237,17 +2283,48 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 
     // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
     if (P.dbg & 4) return;
+    float *const out_seg = (sum_mode ? jobs.sum_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
+    // (the 32 store offsets do not depend on the job: hipcc would compute them once, ahead of the job loop, and spill them)
+    int irow_e = irow0;
+    if constexpr (sum_mode) asm volatile("" : "+v"(irow_e));
+    if (sum_mode && jb > j_first)
+    {
+        // the running sum of the jobs before this one: stored by these very lanes, long ago — the wait costs nothing — and read
+        // back past the CU's vector cache (sc0 sc1), which may still hold the line as the job before last left it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+        {
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int i = irow_e + mt * 32 + (r & 3) + 8 * (r >> 2);
+                const int t = t0 - H + i;
+                const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
+                sv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, voff, 0, 17));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) yreg[mt][r] = sv[r] + yreg[mt][r];
+        }
+    }
+    const bool last_job = jb + 1 == j_end;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
-            const int i = irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int i = irow_e + mt * 32 + (r & 3) + 8 * (r >> 2);
             const int t = t0 - H + i;
             const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, ZV_ST_AUX);
+            // (a running sum that this workgroup reads again stays in L2; everything else leaves for the next launch)
+            if (last_job)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, ZV_ST_AUX);
+            else
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, 0);
         }
+    }
 #ifdef ZV_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ZV_STAMP(11)
@@ -2262,24 +2339,66 @@ bool triple_supported(int Cp, int K, const int *dil, int n_dil)
     return 256 - (K - 1) * (sumd + n_dil) >= 96;          // at least 3/8 of the tile's rows are output
 }
 
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
+// the tile height launch_triple picks: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are
+// enough rows for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
+static void triple_tile(int njobs, int n_cu, const Segs &segs, int rate, int &MT, int &R)
+{
+    const int Lmax = segs.max_rows * rate;
+    const int cfg_env = knob(ZV_TRIPLE_CFG);          // A/B hook: MT*1000 + R
+    R = (long)Lmax * segs.nseg * njobs >= 7000L * n_cu ? 512 : 256;
+    MT = 2;
+    if (cfg_env) { MT = cfg_env / 1000; R = cfg_env % 1000; }
+}
+
+static int triple_halo(const TripleJob &P)
+{
+    int sumd = 0;
+    for (int d = 0; d < P.n_dil; d++) sumd += P.dil[d];
+    return ((P.K - 1) / 2) * (sumd + P.n_dil);
+}
+
+// true when launch_triple(..., sum_out) can run every job of a tile in one workgroup and store only their sum: the form with
+// the weights in LDS on 512-row tiles, and about four rounds of such (three times as long) workgroups — ZV_BLOCK_SUM = 0
+// never, 2 whenever the kernel form allows
+bool triple_can_sum(const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
+{
+    const int env = knob(ZV_BLOCK_SUM), v2_env = knob(ZV_TRIPLE_V2);
+    if (!env || njobs < 2 || njobs > PAIR_MAX_JOBS || !v2_env) return false;
+    int MT, R;
+    triple_tile(njobs, n_cu, segs, rate, MT, R);
+    if (MT != 2 || (R != 512 && !(R == 256 && v2_env == 2))) return false;
+    int hmax = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        if (jobs[i].y != jobs[0].y || !triple_supported(jobs[i].Cp, jobs[i].K, jobs[i].dil, jobs[i].n_dil)) return false;
+        hmax = std::max(hmax, triple_halo(jobs[i]));
+    }
+    const int TM = R - 2 * hmax;
+    if (TM < R / 4) return false;
+    const long wgs = (long)((segs.max_rows * rate + TM - 1) / TM) * segs.nseg;
+    return env == 2 || wgs >= 8L * n_cu;
+}
+
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *sum_out)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
+    if (sum_out && !triple_can_sum(jobs, njobs, n_cu, segs, rate)) return hipErrorInvalidValue;
     const int dbg = knob(ZV_DBG);
-    const int cfg_env = knob(ZV_TRIPLE_CFG);          // A/B hook: MT*1000 + R
     TripleJobs js;
     js.segs = segs;
     js.rate = rate;
     js.interleave = 1;
     js.db_mask = 0;
+    js.sum_out = sum_out;
+    js.njobs = njobs;
+    js.hmax = 0;
+    for (int i = 0; i < njobs; i++) js.hmax = std::max(js.hmax, triple_halo(jobs[i]));
 #ifdef ZV_STAMPS
     js.stamp = knob(ZV_STAMP_CP) == 32;
 #endif
-    // tile height: 512 rows (the halo recompute of the 11-tap branch falls from 1.9x to 1.3x) once there are enough rows
-    // for about eight rounds of such workgroups, else 256 (measured at 512 frames: 100 vs 104 us)
     const int Lmax = segs.max_rows * rate;
-    int R = (long)Lmax * segs.nseg * njobs >= 7000L * n_cu ? 512 : 256, MT = 2;
-    if (cfg_env) { MT = cfg_env / 1000; R = cfg_env % 1000; }
+    int R, MT;
+    triple_tile(njobs, n_cu, segs, rate, MT, R);
     int gx = 1;
     size_t lds = 0;
     for (int i = 0; i < njobs; i++)
@@ -2290,7 +2409,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         if (P.Cp != jobs[0].Cp || !triple_supported(P.Cp, P.K, P.dil, P.n_dil)) return hipErrorInvalidValue;
         int sumd = 0, dmax = 1;
         for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
-        const int h2 = (P.K - 1) / 2, TM = R - 2 * h2 * (sumd + P.n_dil);
+        const int h2 = (P.K - 1) / 2, TM = R - 2 * (sum_out ? js.hmax : h2 * (sumd + P.n_dil));
         gx = std::max(gx, ((Lmax + TM - 1) / TM) * segs.nseg);
         const size_t rows = R + 2 * h2 * dmax + 5 * dmax;
         lds = std::max(lds, rows * (P.Cp * 2 + 16));
@@ -2319,18 +2438,20 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         }
         if (lds2 <= 80 * 1024)
         {
-            js.interleave = knob(ZV_TRIPLE_INTERLEAVE) != 0 ? njobs : 1;
-            const dim3 grid2 = js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid;
+            js.interleave = (knob(ZV_TRIPLE_INTERLEAVE) != 0 && !sum_out) ? njobs : 1;
+            const dim3 grid2 = sum_out ? dim3(round_up(gx, 8), 1, 1) : (js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid);
             auto launch = [&](auto kern, int nth) {
                 hipError_t e = lds2 > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) : hipSuccess;
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
-            if (MT == 4) return launch(resblock_block32_kernel<4, 512>, 256);
-            return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
+            if (sum_out) return R == 512 ? launch(resblock_block32_kernel<2, 512, true>, 512) : launch(resblock_block32_kernel<2, 256, true>, 256);
+            if (MT == 4) return launch(resblock_block32_kernel<4, 512, false>, 256);
+            return R == 512 ? launch(resblock_block32_kernel<2, 512, false>, 512) : launch(resblock_block32_kernel<2, 256, false>, 256);
         }
     }
+    if (sum_out) return hipErrorInvalidValue;          // (triple_can_sum said the form above fits)
 #define ZV_TCASE(mt, r) \
     if (MT == mt && R == r) { hipLaunchKernelGGL((resblock_triple_kernel<32, mt, r>), grid, dim3(64 * (r / 32 / mt)), lds, s, js); return hipGetLastError(); }
     ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
@@ -2455,7 +2576,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
     constexpr int AH = 16384, BH = ntg * 2048;       // bytes of a half unit's operand slice / weight fragments
     constexpr int SLOT = AH + 18432;                 // one ring slot (room for 9 tiles)
     const ConvJob &J = jobs.j[0];
-    const int ng = (gemm_groups_dev(J.Cout_p));
     const int useg = rt / jobs.tps;
     const Seg sg = seg_at(jobs.segs, useg);
     const int L = sg.rows * jobs.rate;

@@ -170,6 +170,7 @@ struct PairJobs
     Segs    segs;
     int     rate;
     int     njobs, kmax;
+    int     interleave;          // > 1: that many jobs read the same input and run interleaved per XCD on one common tiling (grid.z = 1)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
@@ -211,13 +212,17 @@ struct TripleJobs
     int       rate;
     int       interleave;        // resblock_block32_kernel: > 1 = that many jobs share grid.x, interleaved per XCD
     int       db_mask;           // resblock_block32_kernel: bit j = job j keeps two weight buffers in LDS (set by the launcher)
+    float    *sum_out;           // resblock_block32_kernel: non-null = a workgroup runs all `njobs` jobs of its tile and stores only
+    int       njobs, hmax;       //   their sum (out_0 + out_1) + out_2 here, on the common tiling of the widest halo `hmax`
 #ifdef ZV_STAMPS
     int       stamp;
 #endif
 };
 // true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
 bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
+// sum_out (may be null; only when triple_can_sum): the jobs share their input and only (out_0 + out_1) + out_2 is stored, there
+bool       triple_can_sum(const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *sum_out = nullptr);
 
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
 struct OutConvArgs

@@ -30,7 +30,9 @@ namespace zv
     X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 1 one group per XCD, 2 the 9-tile group first */ \
     X(ZV_CONV_LW, 0)           /* 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs */          \
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
+    X(ZV_PAIR_INTERLEAVE, 0)   /* 0 never, 1 batches, 2 always: pair launches whose jobs share their input run the branches interleaved per XCD (measured: 0 … +3 %) */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
+    X(ZV_BLOCK_SUM, 0)         /* 0 never, 1 batches, 2 always: the whole-block kernel runs the three branches of a tile in one workgroup and stores their sum (measured: output conv -0.37 ms, blocks +0.66 ms per batch) */ \
     X(ZV_TRIPLE_CFG, 0)        /* MT * 1000 + R of the whole-block kernel */                                                          \
     X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always: whole-block kernel with its weights in LDS */                         \
     X(ZV_TRIPLE_DB, 1)         /* 0: one weight buffer for every branch */                                                            \

@@ -970,7 +970,11 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 }
                 ycur[jb] = y[jb];
             }
-            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate));
+            // batches: a workgroup runs the three branches of its tile and only their sum is stored (the next launch reads one
+            // tensor); a debug run of one block needs that block's own output
+            const bool sum3 = !no_merge_ && !dbg_here && triple_can_sum(tj, 3, n_cu, fr, rate);
+            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate, sum3 ? y[0] : nullptr));
+            if (sum3) merged_sum = y[0];
         }
         for (int d = 0; d < voc_.n_dil && !whole_block; d++)
         {
