@@ -2000,10 +2000,10 @@ __device__ __forceinline__ void dma_weights32(const void *wsrc, char *wlds, int 
                                          (__attribute__((address_space(3))) void *)(wlds + blk * 1024), 16, 0, 0);
 }
 
-// one conv of the 32-channel block: nb bodies of 8 steps (4 taps x 2 channel halves), A rows and B fragments from LDS,
-// both two steps ahead of the MFMAs that consume them (four register sets in rotation, a scheduling fence per step)
+// one conv of the 32-channel block: K taps x 2 channel halves, A rows and B fragments from LDS, both two steps ahead of the
+// MFMAs that consume them (four register sets in rotation, a scheduling fence per step)
 template <int MT, bool SWAP>
-__device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *ap, int dilRS, const char *wl, int nb)
+__device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *ap, int dilRS, const char *wl, int K)
 {
     constexpr int RS = 32 * 2 + 16;
     half8 a[4][MT], b[4][1];
@@ -2016,25 +2016,25 @@ __device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *
 #define ZV_ST(slot, Z)                                   \
     mfma_step<MT, 1, SWAP, Z>(acc, a[slot], b[slot]);    \
     __builtin_amdgcn_sched_barrier(0);
-#define ZV_BODY32(Z0)                                                                         \
-    {                                                                                         \
-        const char *t1 = ap + dilRS, *t2 = t1 + dilRS, *t3 = t2 + dilRS, *apn = t3 + dilRS;   \
-        ZV_LD(2, t1, 2 * 1024) ZV_ST(0, Z0)                                                   \
-        ZV_LD(3, t1 + 32, 3 * 1024) ZV_ST(1, false)                                           \
-        ZV_LD(0, t2, 4 * 1024) ZV_ST(2, false)                                                \
-        ZV_LD(1, t2 + 32, 5 * 1024) ZV_ST(3, false)                                           \
-        ZV_LD(2, t3, 6 * 1024) ZV_ST(0, false)                                                \
-        ZV_LD(3, t3 + 32, 7 * 1024) ZV_ST(1, false)                                           \
-        ZV_LD(0, apn, 8 * 1024) ZV_ST(2, false)                                               \
-        ZV_LD(1, apn + 32, 9 * 1024) ZV_ST(3, false)                                          \
-        ap = apn;                                                                             \
-        wl += 8 * 1024;                                                                       \
-    }
+    // step s = 2 * tap + channel half: fragments in slot s % 4, requested two steps ahead.  Tap 0 starts the accumulators from
+    // the constant 0; the other K - 1 taps (K odd: triple_supported) go two at a time.  Round 2 walked bodies of four taps,
+    // the last of them on zero weights: one tap in K + 1, 12.5 % of the stage's MFMAs.  The last iteration's two look-ahead
+    // requests read one tap past the end (operand rows and weight-buffer slack that exist) and are never used.
+    const char *t1 = ap + dilRS;
     ZV_LD(0, ap, 0)
     ZV_LD(1, ap + 32, 1024)
-    ZV_BODY32(true)
-    for (int ib = 1; ib < nb; ib++) ZV_BODY32(false)
-#undef ZV_BODY32
+    ZV_LD(2, t1, 2 * 1024) ZV_ST(0, true)
+    ZV_LD(3, t1 + 32, 3 * 1024) ZV_ST(1, false)
+    for (int it = (K - 1) >> 1; it > 0; it--)
+    {
+        const char *t2 = t1 + dilRS, *t3 = t2 + dilRS;
+        ZV_LD(0, t2, 4 * 1024) ZV_ST(2, false)
+        ZV_LD(1, t2 + 32, 5 * 1024) ZV_ST(3, false)
+        ZV_LD(2, t3, 6 * 1024) ZV_ST(0, false)
+        ZV_LD(3, t3 + 32, 7 * 1024) ZV_ST(1, false)
+        t1 = t3;
+        wl += 4 * 1024;
+    }
 #undef ZV_ST
 #undef ZV_LD
 }
@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
-        if (!(P.dbg & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, nb);
+        if (!(P.dbg & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, K);
 #ifdef ZV_STAMPS
         if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
 #endif
@@ -2256,7 +2256,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #endif
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, nb);
+        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
         {
             const float bias = bias2;
             if (edge)
@@ -2333,7 +2333,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 
 bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 {
-    if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || !pair_supported(Cp, K)) return false;
+    if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || !pair_supported(Cp, K) || (K & 1) == 0) return false;
     int sumd = 0;
     for (int d = 0; d < n_dil; d++) sumd += dil[d];
     return 256 - (K - 1) * (sumd + n_dil) >= 96;          // at least 3/8 of the tile's rows are output
