@@ -932,7 +932,7 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
         for (int i = 0; i < njobs; i++)
         {
             const ConvJob &j = jobs[i];
-            const bool ok = g_env != 0 && (g_env == 2 || rows >= 16384) && j.w8 && j.pro == PRO_RAW_F16 && j.Cin_p >= 256 &&
+            const bool ok = g_env != 0 && (g_env == 2 || rows >= 16384) && j.w8 && j.pro == PRO_RAW_F16 && j.Cin_p >= 128 &&
                             conv_gemm_groups(j.Cout_p) >= 1 && !j.out_f16 && (j.ldx & 7) == 0;
             if (!ok)
             {

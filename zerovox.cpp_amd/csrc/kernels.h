@@ -252,6 +252,9 @@ hipError_t launch_stats_finalize(hipStream_t s, const double *part, int nblk, in
 hipError_t launch_norm_apply(hipStream_t s, const float *x, int ldx, int C, const float *stat, int stat_seg, const float *g,
                              const float *b, float *y, int ldy, double *part, int nblk, const Segs &segs);
 
+// out[i] = f16(lrelu(((x0[i] + x1[i]) + x2[i]) * pscale, slope)) over n contiguous elements (x1 = x2 = null: x0[i] * pscale): the
+// operand pre-pass of the upsample convs that run on conv_gemm_kernel
+hipError_t launch_act_f16(hipStream_t s, const float *x0, const float *x1, const float *x2, float pscale, float slope, void *out, size_t n);
 // y = f16(lrelu(((x - mean) * rstd) * g + b, slope)) for C channels (a multiple of 4): the PRO_NORM_ACT operand written out
 // once (PRO_RAW_F16 consumers).  Channels below Cpart get their statistics from `part` (and store them in `stat`), the
 // others read `stat`.  g / b: per-segment stride gb_seg (0 = shared).  yraw (may be null, same layout as y): f16(x) itself — the

@@ -280,6 +280,75 @@ hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// f16 operand pre-pass of the wide polyphase transposed convs of a batch (reference src/hifigan.cpp:281-297: leaky_relu in
+// front of every upsample conv; the MRF mean of the previous stage, :315, rides in the same pass):
+//     out[i] = f16(lrelu(((x0[i] + x1[i]) + x2[i]) * pscale, slope))          (x1 = x2 = null: x0[i] * pscale)
+// — the prologue conv1d_mfma_kernel applies while it stages (PRO_ACT / PRO_SCALE_ACT / PRO_SUM3_ACT), element for element,
+// so that conv_gemm_kernel can move the operand global -> LDS by DMA.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void act_f16_kernel(const float4 *__restrict__ x0, const float4 *__restrict__ x1,
+                                                      const float4 *__restrict__ x2, float pscale, float slope,
+                                                      half4v *__restrict__ out, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride)
+    {
+        float4 v[4], a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const size_t i = i0 + u * stride;
+            if (i >= n4) continue;
+            v[u] = x0[i];
+            if (x1)
+            {
+                a[u] = x1[i];
+                b[u] = x2[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const size_t i = i0 + u * stride;
+            if (i >= n4) continue;
+            float4 x = v[u];
+            if (x1)
+            {
+                x.x = ((x.x + a[u].x) + b[u].x) * pscale;
+                x.y = ((x.y + a[u].y) + b[u].y) * pscale;
+                x.z = ((x.z + a[u].z) + b[u].z) * pscale;
+                x.w = ((x.w + a[u].w) + b[u].w) * pscale;
+            }
+            else
+            {
+                x.x = x.x * pscale;
+                x.y = x.y * pscale;
+                x.z = x.z * pscale;
+                x.w = x.w * pscale;
+            }
+            half4v h;
+            h[0] = (_Float16)(x.x > 0.f ? x.x : x.x * slope);
+            h[1] = (_Float16)(x.y > 0.f ? x.y : x.y * slope);
+            h[2] = (_Float16)(x.z > 0.f ? x.z : x.z * slope);
+            h[3] = (_Float16)(x.w > 0.f ? x.w : x.w * slope);
+            __builtin_nontemporal_store(h, out + i);
+        }
+    }
+}
+
+hipError_t launch_act_f16(hipStream_t s, const float *x0, const float *x1, const float *x2, float pscale, float slope, void *out,
+                          size_t n)
+{
+    if ((n & 3) || !x0 || (!x1) != (!x2)) return hipErrorInvalidValue;
+    const size_t n4 = n >> 2;
+    const size_t wgs = std::min<size_t>((n4 + 1023) / 1024, (size_t)1 << 20);
+    if (wgs == 0) return hipSuccess;
+    hipLaunchKernelGGL(act_f16_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const float4 *)x0, (const float4 *)x1, (const float4 *)x2,
+                       pscale, slope, (half4v *)out, n4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // y[n][o] = dot(W[o][:], x[n][:]) + b[o]   (f32 weights: ggml_mul_mat + ggml_add, reference
 // src/fs2encoder.cpp:77-89,127-128 and src/stylettsdec.cpp:178-179) on the f32-input matrix cores:
 // v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (exact f32, the reference's own FMA accumulation).

@@ -115,7 +115,13 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
     const int OCp = round_up(OC, 16);
     c.Cout = s * OCp;
     c.Cout_p = s * OCp;
-    c.ck = conv_pick_ck(c.Cin_p, 128);      // measured: the 3-input (MRF mean) prologue of these convs prefers 128-channel chunks
+    // batches run the wide ones (at least one group of 8 output tiles, input channels in 64-channel blocks) on conv_gemm_kernel
+    // behind an f16 operand pre-pass; its chains walk 256-channel chunks, so these convs do everywhere (same bits in every regime)
+    // (at least 768 products per output element: measured 225 -> 181 + 15 us and 365 -> 192 + 75 + 50 us (kernel + leftover tiles +
+    // pre-pass) for the 1 536- and 768-deep ones; the 384-deep one 496 -> 364 + 120 us — conv_gemm_kernel's one workgroup per CU
+    // spends a six-unit contraction mostly in its prologue and its 256-KiB epilogue — stays on conv1d_mfma_kernel)
+    const bool gemm_pack = c.Cin_p >= 128 && (c.Cin_p & 63) == 0 && conv_gemm_groups(c.Cout_p) >= 1 && c.K * c.Cin_p >= 768;
+    c.ck = conv_pick_ck(c.Cin_p, gemm_pack ? 256 : 128);      // measured: the 3-input (MRF mean) prologue of these convs prefers 128-channel chunks
     // virtual weight in GGUF conv layout [OC'][IC][K'] (k fastest)
     std::vector<uint16_t> v((size_t)c.Cout * IC * c.K, 0);
     const uint16_t *src = (const uint16_t *)w.data;
@@ -131,6 +137,13 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
     pack_conv_weight(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, c.ck, packed.data());
     c.w = dev_alloc(packed.size() * 2 + 32768);      // slack: as in load_conv
     ZV_HIP(hipMemcpy(c.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    if (gemm_pack)
+    {
+        std::vector<uint16_t> p8(conv_gemm_weight_halfs(c.Cin_p, c.Cout_p, c.K));
+        pack_conv_weight_gemm(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, p8.data());
+        c.w8 = dev_alloc(p8.size() * 2);
+        ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
+    }
     snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.b", idx);
     const GgufTensor &b = g.get(nm);
     if (b.type != GGML_F32 || b.nelements() != OC) fail(ZV_ERR_SHAPE, "tensor %s: expected f32[%d]", nm, OC);
@@ -903,6 +916,18 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 if (i > 0) { j.pro = PRO_SCALE_ACT; j.pscale = 1.0f; }
             }
             j.out = ub;
+            // batches, wide upsample convs: the prologue as a pass of its own (f16 operand tensor, parked in the stage's last xt
+            // buffer — free until the residual blocks run), the conv on conv_gemm_kernel (ZV_UP_GEMM = 0 never, 2 at any length)
+            const int upg = knob(ZV_UP_GEMM);
+            if (up.w8 && upg && knob(ZV_CONV_GEMM) != 0 && (upg == 2 || (long)L >= 16384) && (size_t)up.Cin_p * 2 * L <= Lo * Cp * 4)
+            {
+                ZV_LAUNCH("voc_upsample", 0.0, 0.0, launch_act_f16(stream, (const float *)j.x0, (const float *)j.x1, (const float *)j.x2,
+                                                                   j.pro == PRO_ACT ? 1.0f : j.pscale, j.slope, xt[2], (size_t)L * up.Cin_p));
+                j.x0 = xt[2];
+                j.x1 = j.x2 = nullptr;
+                j.pro = PRO_RAW_F16;
+                j.pscale = 1.0f;
+            }
             // algorithmic: true polyphase MAC count L_in*Cin*Cout*k
             conv(&j, 1, fr, rate, "voc_upsample", 4.0 * La * C * (i == 0 ? 1 : 3) + 4.0 * La * s * Cout + 2.0 * C * Cout * 2 * s,
                  2.0 * La * C * Cout * 2 * s);
