@@ -503,13 +503,112 @@ hipError_t launch_embed(hipStream_t s, const int32_t *ids, const int32_t *puncts
 //   P . V  : wave (qt, dh) accumulates its share of the 32-wide d tiles over the keys in ascending order; the P operand
 //            comes straight from LDS, V rows straight from L2 (128-B segments).
 // v_mfma_f32_32x32x2_f32 is an exact k-ordered f32 fma chain, so every dot product is accumulated in index order.
+// 64 rows x dk floats of one head, global -> LDS: eight 16-byte loads per thread in flight (clamped addresses, rows past the
+// utterance become zeros), then the writes — as four scalars when the destination stride is odd
+template <bool VEC>
+__device__ __forceinline__ void att_stage64(float *dst, int dstride, const float *src, int ld, int key0, int n, int c4n, int tid)
+{
+    const int total = 64 * c4n;
+    for (int base = tid; base < total; base += 256 * 8)
+    {
+        float4 t[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            const int idx = base + u * 256 < total ? base + u * 256 : total - 1;
+            const int r = idx / c4n, c4 = idx - r * c4n;
+            const int key = key0 + r;
+            t[u] = *(const float4 *)(src + (size_t)(key < n ? key : n - 1) * ld + c4 * 4);
+            if (key >= n) t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[u] = r * dstride + c4 * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            if (base + u * 256 >= total) continue;
+            float *d = dst + off[u];
+            if constexpr (VEC)
+                *(float4 *)d = t[u];
+            else
+            {
+                d[0] = t[u].x; d[1] = t[u].y; d[2] = t[u].z; d[3] = t[u].w;
+            }
+        }
+    }
+}
+
+// P . V over the (up to) 64 keys of one staged V block for ND d tiles of a wave: four key pairs per round.  Every LDS read of a
+// round is issued before the first is waited for — as raw ds_read instructions: hipcc sinks a plain (or volatile) read under the
+// select that follows it, a branch and a wait per read, 2 000 cycles per round of 20 MFMAs — at clamped rows; the MFMAs are
+// unguarded (a tile the wave does not own multiplies zeros).
+__device__ __forceinline__ float lds_read_f32(const float *p)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p));
+    return v;
+}
+template <int ND, int NDMAX>
+__device__ __forceinline__ void att_pv_block(floatx16m (&oacc)[NDMAX], const float *pkb, const float *Vs, int dk, int hh, int nk,
+                                             const int (&doff)[NDMAX], const bool (&dok)[NDMAX])
+{
+    const int npb = (nk + 1) >> 1;
+    float a[2][4], bv[2][4][ND];
+    // round = four key pairs; the reads of round r + 1 are issued behind the wait for round r's and ahead of its MFMAs
+    auto issue = [&](float (&ar)[4], float (&br)[4][ND], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int kl = 2 * (s0 + u) + hh;
+            const int klc = kl < nk ? kl : 0;
+            ar[u] = lds_read_f32(pkb + (size_t)klc * 64);
+            const float *vr = Vs + klc * dk;
+#pragma unroll
+            for (int i = 0; i < ND; i++) br[u][i] = lds_read_f32(vr + doff[i]);
+        }
+    };
+    auto arrive = [&](float (&ar)[4], float (&br)[4][ND]) {
+        // one wait for the round; every value passes through an asm statement behind it, so no use can move ahead of it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]));
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < ND; i++) asm volatile("" : "+v"(br[u][i]));
+    };
+    auto consume = [&](float (&ar)[4], float (&br)[4][ND], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const bool kin = 2 * (s0 + u) + hh < nk;
+            ar[u] = kin ? ar[u] : 0.f;
+#pragma unroll
+            for (int i = 0; i < ND; i++) br[u][i] = (kin && dok[i]) ? br[u][i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < ND; i++) oacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[u][i], oacc[i], 0, 0, 0);
+    };
+    issue(a[0], bv[0], 0);
+    for (int s0 = 0; s0 < npb; s0 += 8)
+    {
+        arrive(a[0], bv[0]);
+        if (s0 + 4 < npb) issue(a[1], bv[1], s0 + 4);
+        consume(a[0], bv[0], s0);
+        if (s0 + 4 >= npb) break;
+        arrive(a[1], bv[1]);
+        if (s0 + 8 < npb) issue(a[0], bv[0], s0 + 8);
+        consume(a[1], bv[1], s0 + 4);
+    }
+}
+
 constexpr int ATT_NS_MAX = 144;          // dk <= 288
 constexpr int ATT_NDT_MAX = 5;           // d tiles per wave: dk <= 320
 constexpr int ATT_LDS_MAX = 160 * 1024 - 4096;
 
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                              const float *__restrict__ v, int ld, int dk, float inv_temp,
-                                                             float *__restrict__ o, int ldo, const Segs segs)
+                                                             float *__restrict__ o, int ldo, const Segs segs, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
     __shared__ float redm[4][64];
@@ -538,10 +637,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 #pragma unroll
         for (int j = 0; j < ATT_NS_MAX / 2; j++)
         {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * j < dk) t = *(const float4 *)(qp + 4 * j);
-            qreg[2 * j] = hh ? t.y : t.x;
-            qreg[2 * j + 1] = hh ? t.w : t.z;
+            // (unconditional loads at clamped addresses + a select: a load under a run-time condition becomes a branch with a
+            // wait behind it, one exposed round trip per load)
+            const bool in = 4 * j < dk;
+            const float4 t = *(const float4 *)(qp + (in ? 4 * j : 0));
+            qreg[2 * j] = in ? (hh ? t.y : t.x) : 0.f;
+            qreg[2 * j + 1] = in ? (hh ? t.w : t.z) : 0.f;
         }
     }
 
@@ -550,26 +651,39 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     for (int kt0 = 0; kt0 < nkt; kt0 += 2)
     {
         __syncthreads();
-        for (int idx = tid; idx < 64 * c4n; idx += 256)
-        {
-            const int r = idx / c4n, c4 = idx - r * c4n;
-            const int key = kt0 * 32 + r;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (key < n) t = *(const float4 *)(ks + (size_t)key * ld + c4 * 4);
-            float *d = Ks + r * KSTR + c4 * 4;
-            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
-        }
+        att_stage64<false>(Ks, KSTR, ks, ld, kt0 * 32, n, c4n, tid);
         __syncthreads();
         const int kt = kt0 + kh;
-        if (kt < nkt)
+        if (kt < nkt && !(dbg & 1))
         {
             floatx16m acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
             const float *kr = Ks + (kh * 32 + ql) * KSTR + hh;
+            // groups of four steps (ns is even: a last group of two), the next group's K operands requested ahead of this
+            // group's MFMAs (round 2 guarded every step: a branch and an exposed LDS round trip per MFMA)
+            float kc[4];
 #pragma unroll
-            for (int s = 0; s < ATT_NS_MAX; s++)
-                if (s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qreg[s], acc, 0, 0, 0);
+            for (int j = 0; j < 4; j++) kc[j] = kr[2 * j];
+#pragma unroll
+            for (int s = 0; s < ATT_NS_MAX; s += 4)
+            {
+                if (s + 4 <= ns)
+                {
+                    float kn[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) kn[j] = kr[2 * (s + 4 + j)];       // (past the last group: read, never used)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[j], qreg[s + j], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) kc[j] = kn[j];
+                }
+                else if (s + 2 <= ns)
+                {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[0], qreg[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[1], qreg[s + 1], acc, 0, 0, 0);
+                }
+            }
             // D[row = key (r&3) + 8*(r>>2) + 4*hh][col = query ql]
 #pragma unroll
             for (int r = 0; r < 16; r++)
@@ -582,6 +696,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     __syncthreads();
 
     // ---- softmax over keys: thread (query = tid & 63, part = tid >> 6) walks keys part, part + 4, ...
+    if (!(dbg & 2))
     {
         const int qi = tid & 63, part = tid >> 6;
         float mx = -INFINITY;
@@ -605,7 +720,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     }
     __syncthreads();
 
-    // ---- P . V: wave (qt, dh = kh) owns d tiles dh, dh + 2, ...
+    // ---- P . V: wave (qt, dh = kh) owns d tiles dh, dh + 2, ...; the V rows of 64 keys at a time go through the LDS region the
+    // K tiles used (coalesced 16-byte loads, every one of a block in flight at once — round 2 read V straight from L2, 4 bytes
+    // per lane inside the MFMA loop: a round trip per four key pairs, half of the kernel's time), keys in ascending order as before
     const int ndt = (dk + 31) >> 5;
     floatx16m oacc[ATT_NDT_MAX];
 #pragma unroll
@@ -613,29 +730,32 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[i][r] = 0.f;
     const float *pp = S + qt * 32 + ql;
-    const int npair = (n + 1) >> 1;
-    for (int s0 = 0; s0 < npair; s0 += 4)
+    float *Vs = att_sm;                                    // [64][dk]
+    int doff[ATT_NDT_MAX];
+    bool dok[ATT_NDT_MAX];
+#pragma unroll
+    for (int i = 0; i < ATT_NDT_MAX; i++)
     {
-        float a[4], bv[4][ATT_NDT_MAX];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
+        const int d = (kh + 2 * i) * 32 + ql;
+        dok[i] = kh + 2 * i < ndt && d < dk;
+        doff[i] = dok[i] ? d : 0;
+    }
+    for (int kb = 0; kb < ((dbg & 4) ? 0 : n); kb += 64)
+    {
+        if (kb) __syncthreads();                           // the previous block is consumed (the first: S is complete)
+        if (!(dbg & 16)) att_stage64<true>(Vs, dk, vs, ld, kb, n, c4n, tid);
+        __syncthreads();
+        const int nk = n - kb < 64 ? n - kb : 64;
+        const float *pkb = pp + (size_t)kb * 64;
+        if (dbg & 8) continue;
+        switch ((ndt + 1) >> 1)                            // d tiles of the wider wave (kh = 0): straight-line code per count
         {
-            const int key = 2 * (s0 + u) + hh;
-            const bool kin = key < n;
-            a[u] = kin ? pp[(size_t)key * 64] : 0.f;
-            const float *vr = vs + (size_t)(kin ? key : 0) * ld + ql;
-#pragma unroll
-            for (int i = 0; i < ATT_NDT_MAX; i++)
-            {
-                const int d0 = (kh + 2 * i) * 32;
-                bv[u][i] = (kin && d0 + ql < dk) ? vr[d0] : 0.f;
-            }
+        case 1: att_pv_block<1, ATT_NDT_MAX>(oacc, pkb, Vs, dk, hh, nk, doff, dok); break;
+        case 2: att_pv_block<2, ATT_NDT_MAX>(oacc, pkb, Vs, dk, hh, nk, doff, dok); break;
+        case 3: att_pv_block<3, ATT_NDT_MAX>(oacc, pkb, Vs, dk, hh, nk, doff, dok); break;
+        case 4: att_pv_block<4, ATT_NDT_MAX>(oacc, pkb, Vs, dk, hh, nk, doff, dok); break;
+        default: att_pv_block<5, ATT_NDT_MAX>(oacc, pkb, Vs, dk, hh, nk, doff, dok); break;
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int i = 0; i < ATT_NDT_MAX; i++)
-                if (kh + 2 * i < ndt) oacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][i], oacc[i], 0, 0, 0);
     }
     // D[row = query (r&3) + 8*(r>>2) + 4*hh][col = d ql]
     float *os = o + rb * ldo + h * dk;
@@ -729,7 +849,7 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((n + 63) / 64, H, segs.nseg), dim3(256), lds_mfma, s, q, k, v, ld, dk, inv_temp, o, ldo, segs);
+        hipLaunchKernelGGL(kern, dim3((n + 63) / 64, H, segs.nseg), dim3(256), lds_mfma, s, q, k, v, ld, dk, inv_temp, o, ldo, segs, knob(ZV_DBG) >> 8);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(dk + n) * sizeof(float);
