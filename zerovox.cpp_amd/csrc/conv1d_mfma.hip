@@ -1729,7 +1729,8 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     // workgroups per CU instead of two — measured worth 0.6 %)
     // (CP = 256: exactly K taps — the prefetch one tap past the end reads rows that exist but are never used — so that the
     // 96-row tile of MT = 3 stays under 80 KB: two workgroups per CU)
-    const size_t lds = (size_t)(BM + (Kmax + (CP == 256 ? 0 : (CP >= 128 ? 1 : 4))) * dmax) * (CP * 2 + 16);
+    // (ZV_LDS_PAD: diagnostic — extra bytes of LDS per workgroup, to measure a kernel at a lower occupancy)
+    const size_t lds = (size_t)(BM + (Kmax + (CP == 256 ? 0 : (CP >= 128 ? 1 : 4))) * dmax) * (CP * 2 + 16) + (size_t)knob(ZV_LDS_PAD);
     auto kern = resblock_pair_kernel<CP, MT, MERGE>;
     if (lds > 64 * 1024)
     {

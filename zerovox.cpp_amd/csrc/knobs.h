@@ -40,6 +40,7 @@ namespace zv
     X(ZV_TRIPLE_INTERLEAVE, 1) /* 0: branches not interleaved per XCD */                                                              \
     X(ZV_ATT_SCALAR, 0)        /* 1: scalar attention kernel */                                                                       \
     X(ZV_ATT_MFMA, 0)          /* 1: matrix-core attention kernel whatever the size */                                                \
+    X(ZV_LDS_PAD, 0)           /* diagnostic: extra bytes of LDS per workgroup of the pair kernels (a lower occupancy on purpose) */ \
     X(ZV_STAMP_CP, 0)          /* diagnostic build: channel count of the pair launches that write phase stamps */                     \
     X(ZV_STAMP_CONV, 0)        /* diagnostic build: grid.y of the conv launches that write phase stamps */                            \
     X(ZV_STAMP_CIN, 0)         /* diagnostic build: their input channels */
