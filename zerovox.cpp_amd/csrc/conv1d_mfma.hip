@@ -917,6 +917,163 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
 
 static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs &segs, int rate);
 
+// ---------------------------------------------------------------------------------------------------
+// conv_stream_kernel — the memory-bound polyphase transposed convs of a batch (the last two upsample convs, reference
+// src/hifigan.cpp:281-297 + 22-71: a few hundred MACs per output element against 8-12 bytes moved) as a stream.
+// In conv1d_mfma_kernel every 64-row workgroup of such a conv is a chain of round trips — stage the tile, fetch 36-98 KiB of
+// weight fragments from L2, store, wait for the stores to drain — and the launch's rate is workgroups in flight over that chain
+// (ablations: with its MFMA loop off the last upsample conv takes 429 of its 610 us, stores alone 280).  Here a workgroup
+//   * keeps the weight fragments of its four output tiles in REGISTERS (one 32-channel tile per wave, K * Cin/16 = 12 / 24
+//     fragments) and walks a strip of up to 8 consecutive 64-row tiles with them;
+//   * requests tile i + 1's rows (f32, one tensor: PRO_ACT / PRO_SCALE_ACT) into registers ahead of tile i's MFMAs, converts and
+//     writes them into the other half of a double-buffered LDS tile behind them: one barrier per tile, no staging wait after
+//     the first tile, the stores of tile i drain under tile i + 1.
+// Same prologue arithmetic, same (tap, channel) chain per output element, same epilogue as conv1d_mfma_kernel: same bits.
+template <int NKC>
+__global__ __launch_bounds__(256, NKC == 8 ? 2 : 3) void conv_stream_kernel(const ConvJobs jobs, const int strip)
+{
+    constexpr int K = 3, CIN = 16 * NKC, RS = CIN * 2 + 16, NF = K * NKC, TROWS = 64 + K - 1;
+    constexpr int C4 = CIN / 4, NP = (TROWS * C4 + 255) / 256, TILE_B = TROWS * RS;
+    const ConvJob &J = jobs.j[0];
+    const int useg = blockIdx.x / jobs.tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int s0 = (blockIdx.x - useg * jobs.tps) * strip * 64;
+    if (s0 >= L) return;
+    const size_t row0 = (size_t)sg.row0 * jobs.rate;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (J.Cout_p + 31) >> 5;
+    const int nt_w = blockIdx.y * 4 + wave;
+    const bool n_ok = nt_w < ntiles;
+    const int nt = n_ok ? nt_w : ntiles - 1;                 // (a wave without a tile computes the last one again and stores nothing)
+    half8 wf[NF];
+    {
+        const half8 *wp = (const half8 *)J.w + (size_t)nt * NF * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NF; i++) wf[i] = wp[i * 64];
+    }
+    const int oc = nt * 32 + (lane & 31);
+    const float bias = J.bias ? J.bias[oc] : 0.f;
+    const float *xs = (const float *)J.x0 + row0 * J.ldx;
+    float *outp = (float *)J.out + row0 * J.ldo;
+    const float sc = J.pro == PRO_ACT ? 1.0f : J.pscale, sl = J.slope;
+    const int pad = J.pad;
+
+    float4 v[NP];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+        {
+            const int idx = tid + p * 256 < TROWS * C4 ? tid + p * 256 : TROWS * C4 - 1;
+            const int r = idx / C4, c4 = idx % C4;
+            const int t = m0 - pad + r;
+            v[p] = *(const float4 *)(xs + (size_t)(t < 0 ? 0 : (t < L ? t : L - 1)) * J.ldx + c4 * 4);
+        }
+    };
+    auto write_tile = [&](int buf, int m0) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+        {
+            const int idx = tid + p * 256;
+            if (idx >= TROWS * C4) continue;
+            const int r = idx / C4, c4 = idx % C4;
+            const int t = m0 - pad + r;
+            float4 x = v[p];
+            x.x = x.x * sc;
+            x.y = x.y * sc;
+            x.z = x.z * sc;
+            x.w = x.w * sc;
+            half4 h;
+            h[0] = (_Float16)lrelu(x.x, sl);
+            h[1] = (_Float16)lrelu(x.y, sl);
+            h[2] = (_Float16)lrelu(x.z, sl);
+            h[3] = (_Float16)lrelu(x.w, sl);
+            uint2 pk = *(uint2 *)&h;
+            const bool in = t >= 0 && t < L;
+            pk.x = in ? pk.x : 0u;
+            pk.y = in ? pk.y : 0u;
+            *(uint2 *)(smem + buf * TILE_B + r * RS + c4 * 8) = pk;
+        }
+    };
+
+    int m0 = s0;
+    load_tile(m0);
+    write_tile(0, m0);
+    __syncthreads();
+    const char *abase = smem + (lane & 31) * RS + (lane >> 5) * 16;
+    for (int i = 0; i < strip && m0 < L; i++, m0 += 64)
+    {
+        const bool more = i + 1 < strip && m0 + 64 < L;
+        if (more) load_tile(m0 + 64);
+        __builtin_amdgcn_sched_barrier(0);          // the requests stay ahead of the MFMAs
+        floatx16 acc[2];
+        const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char *ab = abase + (i & 1) * TILE_B;
+#pragma unroll
+        for (int tap = 0; tap < K; tap++)
+#pragma unroll
+            for (int kc = 0; kc < NKC; kc++)
+            {
+                const half8 a0 = *(const half8 *)(ab + tap * RS + kc * 32);
+                const half8 a1 = *(const half8 *)(ab + (32 + tap) * RS + kc * 32);
+                const bool first = tap == 0 && kc == 0;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[tap * NKC + kc], first ? z : acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[tap * NKC + kc], first ? z : acc[1], 0, 0, 0);
+            }
+        if (n_ok)
+        {
+            const int tbase = m0 + 4 * (lane >> 5);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const int t = tbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    const float vv = (acc[mt][r] + bias) * J.escale;
+                    if (t < L) __builtin_nontemporal_store(vv, outp + (size_t)t * J.ldo + oc);
+                }
+        }
+        if (more) write_tile((i + 1) & 1, m0 + 64);
+        __syncthreads();
+    }
+}
+
+// the convs conv_stream_kernel takes: one job, 3 taps, one chunk of 64 / 128 input channels read from ONE f32 tensor, bias-only epilogue
+static bool conv_stream_ok(const ConvJob &j, int njobs, int nt_begin)
+{
+    return njobs == 1 && nt_begin == 0 && (j.pro == PRO_ACT || j.pro == PRO_SCALE_ACT) && j.K == 3 && j.dil == 1 && j.pad == 1 &&
+           (j.Cin_p == 64 || j.Cin_p == 128) && j.ck == j.Cin_p && (j.ldx & 3) == 0 && !j.res && !j.stat_part && !j.eact && !j.out_f16 &&
+           !j.x1 && !j.x2;
+}
+
+static hipError_t launch_conv_stream(hipStream_t s, const ConvJob &job, int n_cu, const Segs &segs, int rate)
+{
+    ConvJobs js;
+    js.j[0] = job;
+    js.j[0].dbg = knob(ZV_DBG);
+    for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
+    js.segs = segs;
+    js.rate = rate;
+    js.nt_begin = 0;
+    js.order = 0;
+    const int Lmax = segs.max_rows * rate;
+    const int ntiles = (job.Cout_p + 31) / 32, gy = (ntiles + 3) / 4;
+    const int occ = job.Cin_p == 128 ? 2 : 3;
+    // strips of 8 tiles while that still leaves about twelve rounds of workgroups, else 4, 2
+    int strip = 8;
+    while (strip > 2 && (long)((Lmax + 64 * strip - 1) / (64 * strip)) * segs.nseg * gy < 12L * occ * n_cu) strip >>= 1;
+    js.tps = (Lmax + 64 * strip - 1) / (64 * strip);
+    const dim3 grid(js.tps * segs.nseg, gy, 1);
+    const size_t lds = (size_t)2 * 66 * (job.Cin_p * 2 + 16);
+    if (job.Cin_p == 128)
+        hipLaunchKernelGGL(conv_stream_kernel<8>, grid, dim3(256), lds, s, js, strip);
+    else
+        hipLaunchKernelGGL(conv_stream_kernel<4>, grid, dim3(256), lds, s, js, strip);
+    return hipGetLastError();
+}
+
 static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, int nt_begin);
 
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
@@ -996,6 +1153,10 @@ static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs
         // element against 8 bytes moved) want workgroups in flight, not weight reuse: measured on the batch, the last
         // three upsample convs take 897 / 595 / 452 us with the tall tiles and 636 / 569 / 416 us with these
         const double ai = 2.0 * jobs[0].K * jobs[0].Cin_p * Cout_p / (4.0 * (jobs[0].Cin_p + Cout_p));
+        // ... and the ones conv_stream_kernel takes run there (ZV_CONV_STREAM = 0 never, 2 at any length)
+        const int st_env = knob(ZV_CONV_STREAM);
+        if (st_env && conv_stream_ok(jobs[0], njobs, nt_begin) && (st_env == 2 || (ai < 200.0 && wgs(1, 1) >= 16L * n_cu)))
+            return launch_conv_stream(s, jobs[0], n_cu, segs, rate);
         // (round 3: 64-row tiles for all of them — the 128 -> 4 x 64 channel one 573 -> 501 us: half the weight stream per row)
         if (ai < 200.0 && wgs(1, 1) >= 16L * n_cu) MT = std::min(MT, 2);
     }

@@ -27,6 +27,7 @@ namespace zv
     X(ZV_CONV_NT, 0)           /* 1 / 2: output tiles per wave of the generic conv kernel */                                          \
     X(ZV_CONV_SINGLE, 1)       /* 0: never the single-utterance MFMA loop, 2: also for one-chunk convs */                             \
     X(ZV_CONV_GEMM, 1)         /* 0 never, 1 batches, 2 always: conv_gemm_kernel for wide convs over an f16 operand tensor */         \
+    X(ZV_CONV_STREAM, 1)       /* 0 never, 1 batches, 2 always: memory-bound 3-tap convs (the last upsample convs) on conv_stream_kernel */ \
     X(ZV_UP_GEMM, 1)           /* 0 never, 1 batches, 2 always: the wide upsample convs behind an f16 operand pass on conv_gemm_kernel */ \
     X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 1 one group per XCD, 2 the 9-tile group first */ \
     X(ZV_CONV_LW, 0)           /* 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs */          \
