@@ -230,17 +230,19 @@ __global__ __launch_bounds__(256) void norm_act_f16_kernel(const float *__restri
     _Float16 *ys = y + (size_t)sg.row0 * ldy + c;
     _Float16 *yr = yraw ? yraw + (size_t)sg.row0 * ldy + c : nullptr;      // f16(x): the operand of a block's 1x1 shortcut conv
     typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-    for (int t0 = rl; t0 < L; t0 += 64)
+    // the rows of a segment are dealt over gridDim.z workgroups in chunks of 128 (every one of them finalises the statistics of
+    // its 64 channels for itself: the same arithmetic, the same values); eight 16-byte loads per thread in flight
+    for (int t0 = blockIdx.z * 128 + rl; t0 < L; t0 += 128 * gridDim.z)
     {
-        float4 v[4];
+        float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 8; u++)
         {
             const int t = t0 + 16 * u;
             v[u] = *(const float4 *)(xs + (size_t)(t < L ? t : L - 1) * ldx);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 8; u++)
         {
             const int t = t0 + 16 * u;
             if (t >= L) continue;
@@ -274,7 +276,10 @@ hipError_t launch_norm_act_f16(hipStream_t s, const float *x, int ldx, int C, co
 {
     if ((C & 3) || (ldx & 3) || (ldy & 3) || segs.nseg < 1 || Cpart > C) return hipErrorInvalidValue;
     if (Cpart > 0 && (segs.max_rows + 31) / 32 > nblk) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_act_f16_kernel, dim3((C + 63) / 64, segs.nseg), dim3(256), 0, s, x, ldx, C, part, nblk, Cpart, eps, stat,
+    // (row chunks per segment: enough workgroups for about eight per CU, at most one per 128 rows)
+    int gz = 1;
+    while (gz < 8 && (long)((C + 63) / 64) * segs.nseg * gz < 2048 && gz * 128 < segs.max_rows) gz <<= 1;
+    hipLaunchKernelGGL(norm_act_f16_kernel, dim3((C + 63) / 64, segs.nseg, gz), dim3(256), 0, s, x, ldx, C, part, nblk, Cpart, eps, stat,
                        stat_seg, ga, be, gb_seg, slope, (_Float16 *)y, ldy, (_Float16 *)yraw, segs);
     return hipGetLastError();
 }
