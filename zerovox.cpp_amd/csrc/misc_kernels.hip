@@ -883,12 +883,23 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     constexpr int LN_MAXE = 12;
     if (C <= 64 * LN_MAXE)
     {
-        float v[LN_MAXE];
+        // (every load unconditional at a clamped column, then selects: a load under a run-time condition becomes a branch with a
+        // wait behind it — 24 + 24 exposed round trips per row in round 2's form of this loop, 12.5 us per launch)
+        float v[LN_MAXE], rv[LN_MAXE], wv[LN_MAXE], bv[LN_MAXE];
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; e++)
+        {
+            const int c = lane + 64 * e, cc = c < C ? c : C - 1;
+            v[e] = xr[cc];
+            rv[e] = rr ? rr[cc] : 0.f;
+            wv[e] = w[cc];
+            bv[e] = b[cc];
+        }
 #pragma unroll
         for (int e = 0; e < LN_MAXE; e++)
         {
             const int c = lane + 64 * e;
-            v[e] = (c < C) ? (rr ? xr[c] + rr[c] : xr[c]) : 0.f;
+            v[e] = (c < C) ? (rr ? v[e] + rv[e] : v[e]) : 0.f;
         }
         double s = 0.0;
 #pragma unroll
@@ -914,8 +925,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
             if (c < C)
             {
                 float t = (v[e] - mean) * scale;
-                t = w[c] * t;
-                y[row * ldy + c] = t + b[c];
+                t = wv[e] * t;
+                y[row * ldy + c] = t + bv[e];
             }
         }
         for (int c = C + lane; c < Cp; c += 64) y[row * ldy + c] = 0.f;
@@ -1075,13 +1086,47 @@ __global__ void lr_gather_kernel(const float *__restrict__ feat, int ld, const i
     for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = live ? src[c] : 0.f;
 }
 
+// the same gather, 16 frames per workgroup: the utterance's cumulative durations are read into LDS once (coalesced) and searched
+// there — the kernel above walks them in global memory, eight dependent round trips per frame — and the rows move in 16-byte pieces
+__global__ __launch_bounds__(256) void lr_gather16_kernel(const float *__restrict__ feat, int ld, const int32_t *__restrict__ cum, int C,
+                                                          float *__restrict__ hidden, int ldh, const Segs tokens, const Segs frames)
+{
+    extern __shared__ int32_t lr_cs[];
+    const Seg tk = seg_at(tokens, blockIdx.y), fr = seg_at(frames, blockIdx.y);
+    const int f0 = blockIdx.x * 16;
+    if (f0 >= fr.rows) return;
+    const int n = tk.rows;
+    for (int i = threadIdx.x; i < n; i += 256) lr_cs[i] = cum[tk.row0 + i];
+    __syncthreads();
+    const int f = f0 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+    if (f >= fr.rows) return;
+    int lo = 0, hi = n;                  // first token i with cum[i] > f
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (lr_cs[mid] > f) hi = mid; else lo = mid + 1;
+    }
+    const bool live = lo < n;
+    const float4 *src = (const float4 *)(feat + ((size_t)tk.row0 + (live ? lo : 0)) * ld);
+    float4 *dst = (float4 *)(hidden + ((size_t)fr.row0 + f) * ldh);
+    for (int c4 = l16; c4 < (C >> 2); c4 += 16)
+    {
+        const float4 v = src[c4];
+        dst[c4] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int C, float *hidden,
                                    int ldh, int32_t *cum, int32_t *n_frames, const Segs &tokens, const Segs &frames)
 {
     if (tokens.nseg != frames.nseg || tokens.nseg < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(lr_scan_kernel, dim3(tokens.nseg), dim3(1024), 0, s, logdur, cum, n_frames, tokens, frames);
-    hipLaunchKernelGGL(lr_gather_kernel, dim3(frames.max_rows, frames.nseg), dim3(256), 0, s, feat, ld, cum, C, hidden, ldh, tokens,
-                       frames);
+    if ((C & 3) == 0 && (ld & 3) == 0 && (ldh & 3) == 0 && (size_t)tokens.max_rows * 4 <= 48 * 1024 && tokens.max_rows >= 1)
+        hipLaunchKernelGGL(lr_gather16_kernel, dim3((frames.max_rows + 15) / 16, frames.nseg), dim3(256), (size_t)tokens.max_rows * 4, s,
+                           feat, ld, cum, C, hidden, ldh, tokens, frames);
+    else
+        hipLaunchKernelGGL(lr_gather_kernel, dim3(frames.max_rows, frames.nseg), dim3(256), 0, s, feat, ld, cum, C, hidden, ldh, tokens,
+                           frames);
     return hipGetLastError();
 }
 
