@@ -559,18 +559,16 @@ __device__ __forceinline__ void att_pv_block(floatx16m (&oacc)[NDMAX], const flo
 {
     const int npb = (nk + 1) >> 1;
     float a[2][4], bv[2][4][ND];
-    // round = four key pairs; the reads of round r + 1 are issued behind the wait for round r's and ahead of its MFMAs
-    auto issue = [&](float (&ar)[4], float (&br)[4][ND], int s0) {
+    // round = four key pairs.  A wave issues in order: the reads and address arithmetic of round r + 1 and the selects of pair
+    // u + 1 sit BETWEEN the MFMAs of pair u, where they issue under the matrix pipe's 64 cycles per MFMA — grouped in front of the
+    // round's 20 MFMAs (this loop's first form) they ran with the pipe idle: 2 000 cycles per round for 1 280 of matrix work
+    auto issue_pair = [&](float &ar, float (&br)[ND], int s0, int u) {
+        const int kl = 2 * (s0 + u) + hh;
+        const int klc = kl < nk ? kl : 0;
+        ar = lds_read_f32(pkb + (size_t)klc * 64);
+        const float *vr = Vs + klc * dk;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-        {
-            const int kl = 2 * (s0 + u) + hh;
-            const int klc = kl < nk ? kl : 0;
-            ar[u] = lds_read_f32(pkb + (size_t)klc * 64);
-            const float *vr = Vs + klc * dk;
-#pragma unroll
-            for (int i = 0; i < ND; i++) br[u][i] = lds_read_f32(vr + doff[i]);
-        }
+        for (int i = 0; i < ND; i++) br[i] = lds_read_f32(vr + doff[i]);
     };
     auto arrive = [&](float (&ar)[4], float (&br)[4][ND]) {
         // one wait for the round; every value passes through an asm statement behind it, so no use can move ahead of it
@@ -580,30 +578,33 @@ __device__ __forceinline__ void att_pv_block(floatx16m (&oacc)[NDMAX], const flo
 #pragma unroll
             for (int i = 0; i < ND; i++) asm volatile("" : "+v"(br[u][i]));
     };
-    auto consume = [&](float (&ar)[4], float (&br)[4][ND], int s0) {
+    auto select_pair = [&](float &ar, float (&br)[ND], int s0, int u) {
+        const bool kin = 2 * (s0 + u) + hh < nk;
+        ar = kin ? ar : 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; i++) br[i] = (kin && dok[i]) ? br[i] : 0.f;
+    };
+    auto round = [&](float (&ac)[4], float (&bc)[4][ND], float (&an)[4], float (&bn)[4][ND], int s0) {
+        const bool more = s0 + 4 < npb;
+        arrive(ac, bc);
+        select_pair(ac[0], bc[0], s0, 0);
 #pragma unroll
         for (int u = 0; u < 4; u++)
         {
-            const bool kin = 2 * (s0 + u) + hh < nk;
-            ar[u] = kin ? ar[u] : 0.f;
+            if (more) issue_pair(an[u], bn[u], s0 + 4, u);
+            if (u < 3) select_pair(ac[u + 1], bc[u + 1], s0, u + 1);
 #pragma unroll
-            for (int i = 0; i < ND; i++) br[u][i] = (kin && dok[i]) ? br[u][i] : 0.f;
+            for (int i = 0; i < ND; i++) oacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u][i], oacc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int i = 0; i < ND; i++) oacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[u][i], oacc[i], 0, 0, 0);
     };
-    issue(a[0], bv[0], 0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) issue_pair(a[0][u], bv[0][u], 0, u);
     for (int s0 = 0; s0 < npb; s0 += 8)
     {
-        arrive(a[0], bv[0]);
-        if (s0 + 4 < npb) issue(a[1], bv[1], s0 + 4);
-        consume(a[0], bv[0], s0);
+        round(a[0], bv[0], a[1], bv[1], s0);
         if (s0 + 4 >= npb) break;
-        arrive(a[1], bv[1]);
-        if (s0 + 8 < npb) issue(a[0], bv[0], s0 + 8);
-        consume(a[1], bv[1], s0 + 4);
+        round(a[1], bv[1], a[0], bv[0], s0 + 4);
     }
 }
 
@@ -634,30 +635,62 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     float *S = att_sm + 64 * KSTR + ((64 * KSTR) & 1);     // [n_pad][64]
     const int nkt = (n + 31) >> 5;
 
-    // ---- this lane's Q fragment: B[k = 2s + hh][col = query ql]
+    // ---- this lane's Q fragment: B[k = 2s + hh][col = query ql].  The 64 query rows go through the K region first (coalesced
+    // 16-byte loads, all in flight at once): read straight from memory, a lane's fragment is 66 loads of 16 bytes at a row's stride,
+    // 64 separate segments per instruction.  (Rows past the utterance are zeros; their scores are never used.)
     float qreg[ATT_NS_MAX];
-    {
-        const int qrow = min(q0 + qt * 32 + ql, n - 1);
-        const float *qp = qs + (size_t)qrow * ld;
+    const int c4n = dk >> 2;
+    // a 64-row block of K or V in registers: requested a phase ahead of the barrier pair that lets it into LDS
+    constexpr int ATT_NPV = (64 * (2 * ATT_NS_MAX / 4) + 255) / 256;
+    float4 vpre[ATT_NPV];
+    const int vtotal = 64 * c4n;
+    auto blk_load = [&](const float *src, int kb) {
 #pragma unroll
-        for (int j = 0; j < ATT_NS_MAX / 2; j++)
+        for (int p = 0; p < ATT_NPV; p++)
         {
-            // (unconditional loads at clamped addresses + a select: a load under a run-time condition becomes a branch with a
-            // wait behind it, one exposed round trip per load)
-            const bool in = 4 * j < dk;
-            const float4 t = *(const float4 *)(qp + (in ? 4 * j : 0));
-            qreg[2 * j] = in ? (hh ? t.y : t.x) : 0.f;
-            qreg[2 * j + 1] = in ? (hh ? t.w : t.z) : 0.f;
+            const int idx = tid + p * 256 < vtotal ? tid + p * 256 : vtotal - 1;
+            const int r = idx / c4n, c4 = idx - r * c4n;
+            const int key = kb + r;
+            vpre[p] = *(const float4 *)(src + (size_t)(key < n ? key : n - 1) * ld + c4 * 4);
+        }
+    };
+    blk_load(ks, 0);            // the first K block travels under the Q rows
+    {
+        att_stage64<false>(Ks, KSTR, qs, ld, q0, n, c4n, tid);
+        __syncthreads();
+        const float *qp = Ks + (qt * 32 + ql) * KSTR + hh;
+#pragma unroll
+        for (int j = 0; j < ATT_NS_MAX; j++)
+        {
+            const int jc = j < ns ? j : 0;
+            qreg[j] = lds_read_f32(qp + 2 * jc);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < ATT_NS_MAX; j++)
+        {
+            asm volatile("" : "+v"(qreg[j]));
+            qreg[j] = j < ns ? qreg[j] : 0.f;
         }
     }
 
-    // ---- scores
-    const int c4n = dk >> 2;
+    // ---- scores (the loop's first barrier also ends the reads of the Q rows above)
     for (int kt0 = 0; kt0 < nkt; kt0 += 2)
     {
         __syncthreads();
-        att_stage64<false>(Ks, KSTR, ks, ld, kt0 * 32, n, c4n, tid);
+#pragma unroll
+        for (int p = 0; p < ATT_NPV; p++)
+        {
+            const int idx = tid + p * 256;
+            if (idx >= vtotal) continue;
+            const int r = idx / c4n, c4 = idx - r * c4n;
+            const float4 t = kt0 * 32 + r < n ? vpre[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *d = Ks + r * KSTR + c4 * 4;
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        }
         __syncthreads();
+        if (kt0 + 2 < nkt) blk_load(ks, (kt0 + 2) * 32);      // the next block under this block's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         const int kt = kt0 + kh;
         if (kt < nkt && !(dbg & 1))
         {
@@ -699,6 +732,21 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
         }
     }
     __syncthreads();
+
+    // the V rows of the first 64 keys are requested now and travel under the softmax; every later block under the MFMAs of the
+    // block before it
+    auto v_write = [&](int kb) {
+#pragma unroll
+        for (int p = 0; p < ATT_NPV; p++)
+        {
+            const int idx = tid + p * 256;
+            if (idx >= vtotal) continue;
+            const int r = idx / c4n, c4 = idx - r * c4n;
+            *(float4 *)(att_sm + r * dk + c4 * 4) = kb + r < n ? vpre[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (!(dbg & (4 | 16))) blk_load(vs, 0);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- softmax over keys: thread (query = tid & 63, part = tid >> 6) walks keys part, part + 4, ...
     if (!(dbg & 2))
@@ -748,8 +796,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     for (int kb = 0; kb < ((dbg & 4) ? 0 : n); kb += 64)
     {
         if (kb) __syncthreads();                           // the previous block is consumed (the first: S is complete)
-        if (!(dbg & 16)) att_stage64<true>(Vs, dk, vs, ld, kb, n, c4n, tid);
+        if (!(dbg & 16)) v_write(kb);
         __syncthreads();
+        if (!(dbg & 16) && kb + 64 < n) blk_load(vs, kb + 64);
+        __builtin_amdgcn_sched_barrier(0);
         const int nk = n - kb < 64 ? n - kb : 64;
         const float *pkb = pp + (size_t)kb * 64;
         if (dbg & 8) continue;
