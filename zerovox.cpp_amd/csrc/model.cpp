@@ -844,6 +844,10 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
     int rate = 1;
     int C = voc_.in_conv.Cout;
     float *c0 = arena_.take_n<float>(L * voc_.in_conv.Cout_p);
+    // batches: the first upsample conv runs on conv_gemm_kernel over an f16 operand tensor (see below) — the input conv writes it
+    const int upg0 = knob(ZV_UP_GEMM);
+    const bool c0_f16 = dbg_layer.kind < 0 && voc_.n_up > 0 && voc_.ups[0].w8 && upg0 && knob(ZV_CONV_GEMM) != 0 &&
+                        (upg0 == 2 || (long)L >= 16384) && voc_.ups[0].Cin_p == voc_.in_conv.Cout_p;
 
     // V0: (mel - mean) / scale -> input conv k7 + bias            (src/hifigan.cpp:242-265)
     {
@@ -854,6 +858,12 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
         j.pa = voc_.mean;
         j.pb = voc_.scale;
         j.out = c0;
+        if (c0_f16)
+        {   // the only reader is the first upsample conv on conv_gemm_kernel: its operand f16(lrelu(c0, 0.1)) straight from here
+            j.eact = 1;
+            j.oslope = 0.1f;
+            j.out_f16 = 1;
+        }
         conv(&j, 1, fr, rate, "voc_input_conv", conv_bytes(La, M, C, j.K, false), conv_flops(La, M, C, j.K));
         if (dbg_layer.kind == ZV_LAYER_VOC_INPUT)
         {
@@ -919,7 +929,12 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             // batches, wide upsample convs: the prologue as a pass of its own (f16 operand tensor, parked in the stage's last xt
             // buffer — free until the residual blocks run), the conv on conv_gemm_kernel (ZV_UP_GEMM = 0 never, 2 at any length)
             const int upg = knob(ZV_UP_GEMM);
-            if (up.w8 && upg && knob(ZV_CONV_GEMM) != 0 && (upg == 2 || (long)L >= 16384) && (size_t)up.Cin_p * 2 * L <= Lo * Cp * 4)
+            if (i == 0 && c0_f16)
+            {
+                j.x0 = c0;
+                j.pro = PRO_RAW_F16;
+            }
+            else if (up.w8 && upg && knob(ZV_CONV_GEMM) != 0 && (upg == 2 || (long)L >= 16384) && (size_t)up.Cin_p * 2 * L <= Lo * Cp * 4)
             {
                 ZV_LAUNCH("voc_upsample", 0.0, 0.0, launch_act_f16(stream, (const float *)j.x0, (const float *)j.x1, (const float *)j.x2,
                                                                    j.pro == PRO_ACT ? 1.0f : j.pscale, j.slope, xt[2], (size_t)L * up.Cin_p));
