@@ -417,7 +417,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[3]%s: per GPU a batch of %d mixed-length utterances (32..256 phonemes), "
                                    "T = %d frames each, full fs2encoder -> stylettsdec -> hifigan, host ids in / host wav out "
                                    "(H2D + D2H inside the timed region), one launch per kernel for the whole batch (the last vocoder stage's residual "
-                                   "blocks + output conv in 4 utterance groups, each group's waveform download under the next group's kernels), %s" %
+                                   "blocks + output conv in 8 utterance groups, each group's waveform download under the next group's kernels), %s" %
                                    (" x %d GPUs = configs[4]" % world if world > 1 else "", len(utts), T,
                                     ("eager launches" if args.no_graph else "hipGraph replay") +
                                     ("" if args.no_pipeline or depth == 1 else "; %d batches in flight (step k enqueued before step k - %d is waited for)" % (depth, depth - 1))),

@@ -284,7 +284,7 @@ class Model
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
     int  voc_group_ = 0;          // ZV_VOC_GROUP=G: utterances per vocoder pass of a batch (0 = all at once)
-    int  tail_groups_ = 4;        // ZV_TAIL_GROUPS=G: utterance groups of a batch's last vocoder stage (0 / 1 = no split)
+    int  tail_groups_ = 8;        // ZV_TAIL_GROUPS=G: utterance groups of a batch's last vocoder stage (0 / 1 = no split)
     bool skip_launch_ = false;    // vocode_group: the launches of the part that is not asked for are skipped
     hipStream_t copy_stream_ = nullptr;
     std::vector<hipEvent_t> tail_events_;
