@@ -448,9 +448,21 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
         hipStream_t cs = M.copy_stream();
         pb.gb.assign(G + 1, n_utt);
         pb.gb[0] = 0;
+        // Batches in flight on different lanes share the GPU kernel by kernel; left alone they advance side by side and end
+        // together, and the card idles while the host turns both around (kernel trace: 1.3-2.0 ms without a kernel after every
+        // pair of batches).  ZV_LANE_ORDER = 1: a batch's head (everything up to the last vocoder stage) starts when the batch
+        // before it (on another lane) has finished ITS head — the batches end a tail apart; 2: when it has finished altogether.
+        const int order = zv::knob(zv::ZV_LANE_ORDER);
+        if (order && M.order_last_lane() >= 0 && M.order_last_lane() != lane)
+            ZV_HIP(hipStreamWaitEvent(M.stream, M.order_event(M.order_last_lane(), order == 2 ? 1 : 0), 0));
         if (G <= 1)
         {
             M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
+            if (order)
+            {
+                ZV_HIP(hipEventRecord(M.order_event(lane, 0), M.stream));
+                ZV_HIP(hipEventRecord(M.order_event(lane, 1), M.stream));
+            }
             ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
             ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
             ZV_HIP(hipEventRecord(M.tail_event(1), M.stream));
@@ -458,6 +470,7 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
         else
         {
             M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
+            if (order) ZV_HIP(hipEventRecord(M.order_event(lane, 0), M.stream));
             ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
             for (int g = 1; g < G; g++)               // contiguous groups of about wav_bytes / G each
             {
@@ -475,7 +488,9 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
                 ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
                 ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
             }
+            if (order) ZV_HIP(hipEventRecord(M.order_event(lane, 1), M.stream));
         }
+        if (order) M.set_order_last_lane(lane);
     }
     catch (...)
     {

@@ -19,6 +19,7 @@ namespace zv
     X(ZV_MERGE_SEQ, 1)         /* 0: the 256-channel stage's MRF sum by one three-branch workgroup per tile instead of three launches */ \
     X(ZV_MERGE_MAXC, 256)      /* widest stage whose last dilation pair stores the merged sum (batches) */                            \
     X(ZV_VOC_GROUP, 0)         /* G > 0: the vocoder runs G utterances at a time (experiment) */                                      \
+    X(ZV_LANE_ORDER, 0)        /* batches in flight on different lanes: 0 share the GPU freely, 1 a batch's head waits for the previous batch's head, 2 for all of it */ \
     X(ZV_TAIL_GROUPS, 8)       /* utterance groups of a batch's last vocoder stage */                                                 \
     X(ZV_ARENA_FILL, 0)        /* byte a fresh activation arena is filled with (255: NaN patterns) */                                 \
     X(ZV_DEC_PREPASS, -1)      /* -1 auto, 0 decoder convs normalise on the fly, 1 f16 operand pass */                                \

@@ -479,6 +479,8 @@ Model::~Model()
         for (hipEvent_t e : tail_events_) hipEventDestroy(e);
         if (copy_stream_) hipStreamDestroy(copy_stream_);
     }
+    for (hipEvent_t e : order_events_) hipEventDestroy(e);
+    order_events_.clear();
     for (Lane &l : lanes_)
     {
         if (l.copy_stream) hipStreamSynchronize(l.copy_stream);
@@ -497,6 +499,18 @@ hipStream_t Model::copy_stream()
 {
     if (!copy_stream_) ZV_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
     return copy_stream_;
+}
+
+hipEvent_t Model::order_event(int lane, int which)
+{
+    const int i = 2 * lane + which;
+    while ((int)order_events_.size() <= i)
+    {
+        hipEvent_t e;
+        ZV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        order_events_.push_back(e);
+    }
+    return order_events_[i];
 }
 
 hipEvent_t Model::tail_event(int i)

@@ -110,6 +110,10 @@ class Model
     // second stream + events for the waveform download of a finished group under the next group's kernels
     hipStream_t copy_stream();
     hipEvent_t  tail_event(int i);
+    // ordering of batches in flight on different lanes (ZV_LANE_ORDER): per lane the events "head done" (0) and "all kernels done" (1)
+    hipEvent_t  order_event(int lane, int which);
+    int         order_last_lane() const { return order_last_lane_; }
+    void        set_order_last_lane(int l) { order_last_lane_ = l; }
     int         tail_groups() const { return tail_groups_; }
     void decode_dev(const Batch &b, const float *d_hidden, const float *d_styles, float *d_mel);
     // taps are device pointers inside the arena (token rows as in ids), valid until the next call;
@@ -279,6 +283,8 @@ class Model
     void  *pinned_ = nullptr;
     size_t pinned_cap_ = 0;
     int  cur_lane_ = 0;
+    int  order_last_lane_ = -1;
+    std::vector<hipEvent_t> order_events_;
     void stash_lane();
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
