@@ -314,7 +314,9 @@ static void scatter_out(const char *pin_wav, const size_t *off, float *const *wa
 {
     size_t total = 0;
     for (uint32_t u = a; u < b; u++) total += (size_t)T[u] * hop * 4;
-    const unsigned nth = total > ((size_t)8 << 20) ? 4u : 1u;
+    // (a group of the 8-group tail is 5 MB: with the old 8 MB threshold every group went out on one thread, 4 ms per batch between
+    // a batch's end and the next batch's start on that lane)
+    const unsigned nth = total > ((size_t)1 << 20) ? 4u : 1u;
     auto work = [&](unsigned k) {
         for (uint32_t u = a + k; u < b; u += nth) memcpy(wav[u], pin_wav + off[u], (size_t)T[u] * hop * 4);
     };
