@@ -168,7 +168,7 @@ def test_batch_regime_kernels_vs_reference_golden(ckpt, fixture):
     z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
-    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_MERGE_ALWAYS=1, ZV_CONV_LW=2, ZV_PAIR_INTERLEAVE=2, ZV_BLOCK_SUM=2, ZV_UP_GEMM=2, ZV_CONV_GEMM=2, ZV_CONV_STREAM=2):
+    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_MERGE_ALWAYS=1, ZV_CONV_LW=2, ZV_PAIR_INTERLEAVE=2, ZV_BLOCK_SUM=2, ZV_UP_GEMM=2, ZV_CONV_GEMM=2, ZV_CONV_STREAM=2, ZV_BLOCK64=-11, ZV_BLOCK64_ALL=1):
         m = capi.Model(path, 0)
         wav = m.vocode(mel)
         m.close()
@@ -238,6 +238,9 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       ("pair64_ring", {"ZV_PAIR64_RING": "2"}), ("pair64_ring_no_merge", {"ZV_PAIR64_RING": "2", "ZV_NO_MERGE": "1"}),
                       ("pair64_no_ring", {"ZV_PAIR64_RING": "0"}),
                       ("upsample_gemm", {"ZV_UP_GEMM": "2", "ZV_CONV_GEMM": "2"}), ("upsample_no_gemm", {"ZV_UP_GEMM": "0"}),
+                      ("block64_3_whole", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1", "ZV_BLOCK64_ALL": "1"}), ("block64_3_two_pairs", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1", "ZV_BLOCK64_ALL": "0"}),
+                      ("block64_3_no_merge", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2"}), ("block64_11", {"ZV_BLOCK64": "-11", "ZV_PAIR64_RING": "2"}),
+                      ("no_block64", {"ZV_BLOCK64": "0", "ZV_PAIR64_RING": "2"}),
                       ("upsample_stream", {"ZV_CONV_STREAM": "2"}), ("upsample_no_stream", {"ZV_CONV_STREAM": "0"}),
                       ("block_sum", {"ZV_TRIPLE_V2": "2", "ZV_BLOCK_SUM": "2"}),
                       ("block_sum_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512", "ZV_BLOCK_SUM": "2"}),

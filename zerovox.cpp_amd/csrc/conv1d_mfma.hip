@@ -1827,6 +1827,18 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
                         const float v = (acc[mt][nt][r] + bias) + resv[mt][nt][r];
                         msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
                     }
+                    if (jb == 0 && jobs.merge_init)
+                    {
+                        // the sum's first term comes from memory (a branch that ran as a whole block): (init + out_0) + out_1
+                        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+                            (void *)(jobs.merge_init + (size_t)sg.row0 * jobs.rate * CP + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+                        float iv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            iv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+#pragma unroll
+                        for (int r = 0; r < 16; r++) msum[mt][nt][r] = iv[r] + msum[mt][nt][r];
+                    }
                     if (jb == jobs.njobs - 1)
 #pragma unroll
                         for (int r = 0; r < 16; r++)
@@ -1867,6 +1879,282 @@ static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// resblock_block64_kernel — SEVERAL dilation pairs of a 64-channel residual block in one launch, for the branches whose halo is
+// small (3 taps: 2 rows per pair and dilation step): resblock_pair64_kernel's machinery (weights of every conv through the
+// four-slot LDS ring as ONE stream over all the pairs, both operands from LDS, 64 x 64 per wave) around resblock_block32_kernel's
+// data flow (the f32 tile stays in registers in the accumulator layout — it is the residual operand of every pair —, the f16
+// operand tile is regenerated in LDS per pair, every conv runs over the full 256-row tile as a zero-padded sequence and only
+// the TM = 256 - 2H centre rows are stored).  The branch's tensor crosses HBM once per block instead of once per pair.
+// Same operations in the same order per output element as the pair kernels: same bits.
+__global__ __launch_bounds__(256, 2) void resblock_block64_kernel(const TripleJobs jobs)
+{
+    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
+    constexpr int CHUNK = 8 * 1024;
+    const TripleJob &P = jobs.j[blockIdx.z];
+    const int K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int sumd = 0, dmax = 1;
+    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+    const int H = h2 * (sumd + nd);
+    const int TM = BM - 2 * H;
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
+    const int XM = h2 * dmax;                         // zero margin of the operand region on either side of the tile
+    const int xrows = BM + 2 * XM + 2 * dmax;         // + slack: the last tap's look-ahead reads one tap past the end
+    const bool edge = t0 - H < 0 || t0 - H + BM > L;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char *ring = smem + jobs.ring_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + hh * 16;
+    const char *bl = ring + lane * 16;
+    const int nchunk = 2 * K * nd;                    // the block's weight stream: per pair conv1's taps, then conv2's
+    // chunk g -> ring slot g & 3; base pointers of the (at most six) convs in scalar registers
+    uint32_t wlo[2 * TRIPLE_MAX_DIL], whi[2 * TRIPLE_MAX_DIL];
+#pragma unroll
+    for (int c = 0; c < 2 * TRIPLE_MAX_DIL; c++)
+    {
+        const int d = c >> 1 < nd ? c >> 1 : 0;
+        const uint64_t a = (uint64_t)((c & 1) ? P.w2[d] : P.w1[d]) + wave * 2048;
+        wlo[c] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        whi[c] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    }
+    auto issue = [&](int g) {
+        const int c = g / K, tap = g - c * K;         // conv index (2 * pair + conv), tap
+        uint32_t lo = wlo[0], hi = whi[0];
+#pragma unroll
+        for (int q = 1; q < 2 * TRIPLE_MAX_DIL; q++)
+            if (c == q) { lo = wlo[q]; hi = whi[q]; }
+        const char *src = (const char *)((uint64_t)hi << 32 | lo) + (size_t)tap * CHUNK + lane * 16;
+        char *dst = ring + (g & 3) * CHUNK + wave * 2048;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+    // the whole operand region starts as zeros (margins stay zero for the whole kernel; nothing in it is ever uninitialised)
+    for (int i = tid; i < xrows * RS / 16; i += 256) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+    // tile row i <-> time t0 - H + i; register [mt][nt][r]: row wave*64 + mt*32 + (r&3) + 8*(r>>2) + 4*hh, channel nt*32 + (lane&31)
+    float yreg[MT][NT][16];
+    {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        const int voff = ((t0 - H + wave * 32 * MT + 4 * hh) * CP + (lane & 31)) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    yreg[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, voff + nt * 128 + (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
+    }
+    __syncthreads();                                  // zeros written (and the first chunks landed)
+    const float sl = P.slope;
+    int g = 0;
+    floatx16 acc[MT][NT];
+    half8 a[4][MT], b[4][NT];
+#define ZV_LDR(slot, aptr, boff)                                                                                      \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[slot][nt] = *(const half8 *)(bp_ + (boff) + nt * 1024);  \
+    }
+#define ZV_MF(slot, SW, Z)                                \
+    mfma_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);      \
+    __builtin_amdgcn_sched_barrier(0);
+#define ZV_TAP(SW, Z0, tapstride)                                                                         \
+    {                                                                                                     \
+        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
+        ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
+        ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
+        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if (g + 3 < nchunk) issue(g + 3);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ap += (tapstride);                                                                                \
+        bp_ = bn_;                                                                                        \
+        ZV_LDR(0, ap, 0) ZV_MF(2, SW, false)                                                              \
+        ZV_LDR(1, ap + 32, 2 * 1024) ZV_MF(3, SW, false)                                                  \
+        g++;                                                                                              \
+    }
+    for (int d = 0; d < nd; d++)
+    {
+        const int dil = P.dil[d], h1 = h2 * dil;
+        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + BM - 1 (Y is zero outside [0, L): so is X)
+        {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const int i = wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        *(_Float16 *)(smem + (XM + i) * RS + (nt * 32 + (lane & 31)) * 2) = (_Float16)lrelu_max(yreg[mt][nt][r], sl);
+                    }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // (raw: the weight stream stays in flight)
+        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap * dil
+        {
+            const char *ap = abase + (XM - h1) * RS;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+                ZV_LDR(1, ap + 32, 2 * 1024)
+            }
+            ZV_TAP(true, true, dil * RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading X: its rows become XT
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L)
+        {
+            const float *b1 = P.b1[d];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(b1 + nt * 32 + 8 * q + 4 * hh);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                {
+                    const int i = wave * 32 * MT + mt * 32 + (lane & 31);
+                    const int t = t0 - H + i;
+                    const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        uint2 pk = lrelu4_f16(acc[mt][nt][4 * q + 0] + bq[q].x, acc[mt][nt][4 * q + 1] + bq[q].y,
+                                              acc[mt][nt][4 * q + 2] + bq[q].z, acc[mt][nt][4 * q + 3] + bq[q].w, sl);
+                        if (edge)
+                        {
+                            pk.x = in ? pk.x : 0u;
+                            pk.y = in ? pk.y : 0u;
+                        }
+                        *(uint2 *)(smem + (XM + i) * RS + (nt * 32 + 8 * q + 4 * hh) * 2) = pk;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
+        {
+            const char *ap = abase + (XM - h2) * RS;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+                ZV_LDR(1, ap + 32, 2 * 1024)
+            }
+            ZV_TAP(false, true, RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
+        }
+        {
+            const float *b2 = P.b2[d];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                const float bias = b2[nt * 32 + (lane & 31)];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                    {
+                        const float v = (acc[mt][nt][r] + bias) + yreg[mt][nt][r];
+                        if (edge)
+                        {
+                            const int t = t0 - H + wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            yreg[mt][nt][r] = (t >= 0 && t < L) ? v : 0.f;
+                        }
+                        else
+                            yreg[mt][nt][r] = v;
+                    }
+            }
+        }
+        if (d + 1 < nd)
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave is done reading XT before the next X goes over it
+        }
+    }
+#undef ZV_TAP
+#undef ZV_MF
+#undef ZV_LDR
+    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const int i = wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int t = t0 - H + i;
+                const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + nt * 32 + (lane & 31)) * 4 : -4;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][nt][r]), rs_out, voff, 0, ZV_ST_AUX);
+            }
+}
+
+// the blocks resblock_block64_kernel takes: 64 channels, few taps (the halo of n_dil pairs leaves most of the 256-row tile)
+bool block64_supported(int Cp, int K, const int *dil, int n_dil)
+{
+    if (Cp != 64 || K < 3 || (K & 1) == 0 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL) return false;
+    int sumd = 0;
+    for (int d = 0; d < n_dil; d++) sumd += dil[d];
+    return 256 - (K - 1) * (sumd + n_dil) >= 192;          // at least three quarters of the tile's rows are output
+}
+
+hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const Segs &segs, int rate)
+{
+    if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
+    TripleJobs js;
+    js.segs = segs;
+    js.rate = rate;
+    js.interleave = 1;
+    js.db_mask = 0;
+    js.sum_out = nullptr;
+    js.njobs = njobs;
+    js.hmax = 0;
+    const int Lmax = segs.max_rows * rate;
+    int gx = 1, rows_max = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        js.j[i] = jobs[i];
+        js.j[i].dbg = 0;
+        const TripleJob &P = jobs[i];
+        if (!block64_supported(P.Cp, P.K, P.dil, P.n_dil)) return hipErrorInvalidValue;
+        int sumd = 0, dmax = 1;
+        for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+        const int h2 = (P.K - 1) / 2, TM = 256 - 2 * h2 * (sumd + P.n_dil);
+        gx = std::max(gx, ((Lmax + TM - 1) / TM) * segs.nseg);
+        rows_max = std::max(rows_max, 256 + 2 * h2 * dmax + 2 * dmax);
+    }
+    for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
+    js.ring_off = round_up(rows_max * (64 * 2 + 16), 1024);
+    const size_t lds = (size_t)js.ring_off + 4 * 8192;
+    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)resblock_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resblock_block64_kernel, dim3(round_up(gx, 8), 1, njobs), dim3(256), lds, s, js);
+    return hipGetLastError();
+}
+
 // the MFMA loop of the fused kernels walks whole 8-step bodies (CP = 64: also half a body at the end) and at least one
 bool pair_supported(int Cp, int K)
 {
@@ -1902,7 +2190,7 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     return hipGetLastError();
 }
 
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out, const float *merge_init)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
     const int dbg = knob(ZV_DBG), mt_env = knob(ZV_PAIR_MT);
@@ -1911,6 +2199,8 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     js.rate = rate;
     js.njobs = njobs;
     js.merge_out = merge_out;
+    js.merge_init = merge_init;
+    if (merge_init && !merge_out) return hipErrorInvalidValue;
 #ifdef ZV_STAMPS
     js.stamp = knob(ZV_STAMP_CP) && knob(ZV_STAMP_CP) == jobs[0].Cp && !merge_out;
 #endif
@@ -1956,6 +2246,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
             return merge_out ? launch_pair64_ring<true>(s, js, njobs, Lmax, Kmax, dmax) : launch_pair64_ring<false>(s, js, njobs, Lmax, Kmax, dmax);
         }
     }
+    if (merge_init) return hipErrorInvalidValue;          // (only the 64-channel ring kernel's merged form takes a first term from memory)
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
     // 256 channels, batches: 96-row tiles (two thirds of the weight-fragment traffic per row, 10 instead of 16 % of conv2 spent
     // on halo rows at 11 taps; 80 KB of LDS and 234 registers still give two workgroups per CU): 1 010 -> 897 us per launch.

@@ -175,6 +175,7 @@ struct PairJobs
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
     float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
+    const float *merge_init;     // resblock_pair64_kernel<true>: the sum's first term comes from memory: (init + out_0) + out_1
     int     ring_off;            // resblock_pair64_kernel: byte offset of the weight ring in LDS (set by the launcher)
 };
 // true when a ResBlock conv pair with Cp (padded) channels and K taps can run on the fused kernel
@@ -187,7 +188,8 @@ size_t     pair_ring_weight_halfs(int Cp, int K);
 void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
 // merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
 // stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr,
+                       const float *merge_init = nullptr);
 
 // ---- a whole HiFi-GAN residual block (reference src/hifigan.cpp:74-185: the loop over all dilations) in ONE launch:
 // a workgroup keeps a 256-row f32 tile of y in LDS, runs the n_dil fused pairs on it and writes the centre rows once.
@@ -212,6 +214,7 @@ struct TripleJobs
     int       rate;
     int       interleave;        // resblock_block32_kernel: > 1 = that many jobs share grid.x, interleaved per XCD
     int       db_mask;           // resblock_block32_kernel: bit j = job j keeps two weight buffers in LDS (set by the launcher)
+    int       ring_off;          // resblock_block64_kernel: byte offset of the weight ring in LDS (set by the launcher)
     float    *sum_out;           // resblock_block32_kernel: non-null = a workgroup runs all `njobs` jobs of its tile and stores only
     int       njobs, hmax;       //   their sum (out_0 + out_1) + out_2 here, on the common tiling of the widest halo `hmax`
 #ifdef ZV_STAMPS
@@ -220,6 +223,9 @@ struct TripleJobs
 };
 // true when a ResBlock (Cp channels, K taps, these dilations) fits the whole-block kernel
 bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
+// several dilation pairs of a 64-channel block in one launch (resblock_block64_kernel): w1 / w2 in pack_pair_weight_ring layout
+bool       block64_supported(int Cp, int K, const int *dil, int n_dil);
+hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const Segs &segs, int rate);
 // sum_out (may be null; only when triple_can_sum): the jobs share their input and only (out_0 + out_1) + out_2 is stored, there
 bool       triple_can_sum(const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *sum_out = nullptr);

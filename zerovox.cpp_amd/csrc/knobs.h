@@ -34,6 +34,8 @@ namespace zv
     X(ZV_CONV_LW, 0)           /* 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs */          \
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
     X(ZV_PAIR_INTERLEAVE, 0)   /* 0 never, 1 batches, 2 always: pair launches whose jobs share their input run the branches interleaved per XCD (measured: 0 … +3 %) */ \
+    X(ZV_BLOCK64, 3)           /* 64-channel stage of a batch: branches with at most that many taps run their first two dilation pairs in one launch (resblock_block64_kernel); 0 never, negative: at any length */ \
+    X(ZV_BLOCK64_ALL, 0)       /* 1: resblock_block64_kernel runs the first branch's WHOLE block, its output the merged sum's first term (measured: the same time as two of its three pairs) */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
     X(ZV_BLOCK_SUM, 0)         /* 0 never, 1 batches, 2 always: the whole-block kernel runs the three branches of a tile in one workgroup and stores their sum (measured: output conv -0.37 ms, blocks +0.66 ms per batch) */ \
     X(ZV_TRIPLE_CFG, 0)        /* MT * 1000 + R of the whole-block kernel */                                                          \

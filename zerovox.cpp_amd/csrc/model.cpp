@@ -1030,13 +1030,62 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate, sum3 ? y[0] : nullptr));
             if (sum3) merged_sum = y[0];
         }
+        // 64 channels, batches: the first two dilation pairs of the branches with few taps in ONE launch (resblock_block64_kernel:
+        // the branch's tensor crosses HBM once instead of twice; ZV_BLOCK64 = most taps it takes, 0 = never; negative: at any length)
+        bool b64[3] = {false, false, false};
+        bool b64_full0 = false;       // ... and the FIRST branch all three of them: its output is then the first term of the merged MRF sum
+        {
+            const int k64 = knob(ZV_BLOCK64);
+            const int kmax64 = k64 < 0 ? -k64 : k64;
+            const bool merge_later = !no_merge_ && !dbg_here && (knob(ZV_MERGE_ALWAYS) != 0 || Lbatch / 246 >= 4L * n_cu) && Cp <= knob(ZV_MERGE_MAXC);
+            if (fused && !whole_block && Cp == 64 && voc_.n_dil == 3 && kmax64 >= 3 && !dbg_here && (k64 < 0 || Lbatch / 244 >= 4L * n_cu))
+            {
+                TripleJob tj[3];
+                int nj = 0;
+                double bb = 0, ff = 0;
+                for (int jb = 0; jb < 3; jb++)
+                {
+                    const ResPair *rp = &voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil];
+                    if (rp[0].c1.K > kmax64 || !rp[0].r1 || !rp[0].r2 || !rp[1].r1 || !rp[1].r2 || !block64_supported(Cp, rp[0].c1.K, voc_.dil, 2)) continue;
+                    // (the merged launch must be the ring kernel's: only that takes the sum's first term from memory)
+                    const int ring = knob(ZV_PAIR64_RING);
+                    const bool full = jb == 0 && knob(ZV_BLOCK64_ALL) != 0 && merge_later && rp[2].r1 && rp[2].r2 &&
+                                      ring != 0 && (ring == 2 || 2 * (Lbatch / 246) >= 6L * n_cu) &&
+                                      block64_supported(Cp, rp[0].c1.K, voc_.dil, 3);
+                    TripleJob &t = tj[nj++];
+                    memset(&t, 0, sizeof(t));
+                    t.y = ub;
+                    t.out = full ? y[jb] : (float *)xt[jb];
+                    t.n_dil = full ? 3 : 2;
+                    t.Cp = Cp;
+                    t.K = rp[0].c1.K;
+                    t.slope = 0.1f;
+                    if (full) b64_full0 = true;
+                    for (int d = 0; d < t.n_dil; d++)
+                    {
+                        t.w1[d] = rp[d].r1;
+                        t.w2[d] = rp[d].r2;
+                        t.b1[d] = rp[d].c1.bias;
+                        t.b2[d] = rp[d].c2.bias;
+                        t.dil[d] = voc_.dil[d];
+                        bb += conv_bytes(La, C, C, rp[d].c1.K, false) + conv_bytes(La, C, C, rp[d].c2.K, true);
+                        ff += conv_flops(La, C, C, rp[d].c1.K) + conv_flops(La, C, C, rp[d].c2.K);
+                    }
+                    b64[jb] = true;
+                    ycur[jb] = full ? y[jb] : (float *)xt[jb];
+                }
+                if (nj) ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_block64(stream, tj, nj, fr, rate));
+            }
+        }
         for (int d = 0; d < voc_.n_dil && !whole_block; d++)
         {
             ConvJob j1[3], j2[3];
             PairJob pj[3];
             double b1 = 0, f1 = 0, b2 = 0, f2 = 0;
+            int npj = 0;                     // pair jobs of this dilation (the branches resblock_block64_kernel has not covered)
             for (int jb = 0; jb < 3; jb++)
             {
+                if (b64[jb] && (d < 2 || (jb == 0 && b64_full0))) continue;
                 const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
                 const float *yin = ycur[jb];
                 float *yout = fused ? ((d & 1) ? (float *)xt[jb] : y[jb]) : y[jb];
@@ -1061,7 +1110,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 b.ldres = Cp;
                 b.out = y[jb];
                 j2[jb] = b;
-                PairJob &p = pj[jb];
+                PairJob &p = pj[npj++];
                 memset(&p, 0, sizeof(p));
                 p.y = yin;
                 p.out = yout;
@@ -1091,7 +1140,9 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             const bool merge = fused && !no_merge_ && !dbg_here && d == voc_.n_dil - 1 && merge_pays;
             if (merge)
             {
-                float *ms = (pj[0].out != pj[0].y && pj[0].out != pj[1].y && pj[0].out != pj[2].y) ? pj[0].out : nullptr;
+                bool ms_free = true;
+                for (int q = 0; q < npj; q++) ms_free = ms_free && pj[0].out != pj[q].y;
+                float *ms = (ms_free && !(b64_full0 && pj[0].out == ycur[0])) ? pj[0].out : nullptr;
                 if (!ms) fail(ZV_ERR_DEVICE, "internal: no free buffer for the merged MRF sum");
                 if (Cp >= 256 && knob(ZV_MERGE_SEQ) != 0)
                 {
@@ -1108,11 +1159,14 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                     }
                 }
                 else
-                    ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate, ms));
+                    ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2,
+                              launch_pair(stream, pj, npj, n_cu, fr, rate, ms, b64_full0 ? ycur[0] : nullptr));
                 merged_sum = ms;
             }
             else if (fused)
-                ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, 3, n_cu, fr, rate));
+            {
+                if (npj) ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2, launch_pair(stream, pj, npj, n_cu, fr, rate));
+            }
             else
             {
                 conv(j1, 3, fr, rate, "voc_resblock_conv", b1, f1);
