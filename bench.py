@@ -56,7 +56,7 @@ MFMA_PEAK_TF = 2500.0          # dense f16 MFMA peak (same guide)
 UTTS_PER_GPU = 32
 FRAMES = 1024
 SEED_W, SEED_BATCH = 1234, 3
-TRAFFIC_PROFILE = "profiles/r03_resblock_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_resblock_traffic.json"
 KERNEL_SRC = "zerovox.cpp_amd/csrc/conv1d_mfma.hip"
 
 
@@ -96,7 +96,13 @@ def resblock_roofline(stats, psteps, timing_note):
         flops, abytes = st["algo_flops"] / psteps, st["algo_bytes"] / psteps
         traffic = None
         if have_traffic and key in tj.get("per_stage", {}):
-            traffic = tj["per_stage"][key]["hbm_bytes_per_pass"]
+            # the profile's bytes belong to ITS launches: a stage whose launch count differs from what was just timed is a
+            # different schedule (or a hole in the profile's parsing) — not quoted
+            if int(round(tj["per_stage"][key].get("launches_per_pass", -1))) == st["launches"] // psteps:
+                traffic = tj["per_stage"][key]["hbm_bytes_per_pass"]
+            else:
+                tsrc = "refused: %s lists %s launches per pass for stage %s, this run timed %d" % (
+                    TRAFFIC_PROFILE, tj["per_stage"][key].get("launches_per_pass"), key, st["launches"] // psteps)
         t_mfma = flops / (MFMA_PEAK_TF * 1e12) * 1e3
         t_hbm = traffic / (HBM_PEAK_GBS * 1e9) * 1e3 if traffic else None
         bound = "hbm" if (t_hbm is not None and t_hbm > t_mfma) else "mfma"
@@ -221,7 +227,9 @@ def main():
     hop, sr = model.hp.audio_hop_size, model.hp.audio_sampling_rate
     model.set_graph_mode(not args.no_graph)
     call = model.prepare_batch(utts)            # host buffers allocated once; every run() is one zv_synthesize_batch
-    depth = max(1, min(4, int(os.environ.get("ZV_BENCH_LANES", "2"))))       # batches in flight (A/B hook; 2 is what is reported)
+    # batches in flight (A/B hook ZV_BENCH_LANES; 2 is what is reported: with two the GPU never waits for the host —
+    # extra.gpu_idle_ms_per_step, measured below without a profiler — and three or four are 0.5-1.5 % slower)
+    depth = max(1, min(4, int(os.environ.get("ZV_BENCH_LANES", "2"))))
     lanes = [call] + [model.prepare_batch(utts) for _ in range(depth - 1)]   # one set of output buffers per lane
     local_audio_per_step = sum(t * hop / sr for (_, _, _, t) in utts)
 
@@ -232,9 +240,10 @@ def main():
         model.synchronize()
 
     # A serving loop keeps a batch in flight per lane (zv_synthesize_batch_begin / _end): step k is enqueued — input block,
-    # upload, kernels, waveform downloads — before step k - 1 is waited for, so a step's last downloads and copy-out run
-    # under the next step's upload and first kernels.  Every step is a whole batch, host ids in -> host waveforms out, and
-    # all K steps are complete when the timed region ends.  --no-pipeline: one synchronous zv_synthesize_batch per step.
+    # upload, kernels, waveform downloads — before step k - (depth - 1) is waited for, so a step's last downloads and
+    # copy-out run under the next steps' kernels and the GPU always has a batch queued.  Every step is a whole batch, host
+    # ids in -> host waveforms out, and all K steps are complete when the timed region ends.  --no-pipeline: one synchronous
+    # zv_synthesize_batch per step.
     def run_steps(k_steps):
         if args.no_pipeline or depth == 1:
             for _ in range(k_steps):
@@ -254,6 +263,25 @@ def main():
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    # where the GPU had no batch to work on inside the timed region: gaps of the union of the batches' [first operation,
+    # last kernel] intervals (HIP events the library records on the lanes' streams — no profiler attached)
+    gpu_idle = None
+    if not (args.no_pipeline or depth == 1):
+        tl = model.batch_timeline(min(args.steps, 64))
+        if len(tl) >= 2:
+            span0, span1, cover, cur_s, cur_e = tl[0][0], max(e for _, e in tl), 0.0, None, None
+            for s_, e_ in sorted(tl):
+                if cur_e is None or s_ > cur_e:
+                    if cur_e is not None:
+                        cover += cur_e - cur_s
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            cover += cur_e - cur_s
+            gpu_idle = {"batches": len(tl), "span_ms": round(span1 - span0, 3), "idle_ms": round((span1 - span0) - cover, 3),
+                        "idle_ms_per_step": round(((span1 - span0) - cover) / len(tl), 4),
+                        "is": "time inside the span of the last batches' kernels at which no batch had an operation running or queued "
+                              "behind a running one on its stream (zv_batch_timeline: HIP events on the lanes' streams, un-profiled run)"}
     # whole-job rate: sum of audio over ranks / max of wall over ranks
     value = sharding.aggregate_throughput(args.steps * local_audio_per_step, dt)
     rank_ms = {"min": 1e3 * dt / args.steps, "max": 1e3 * dt / args.steps}
@@ -298,6 +326,8 @@ def main():
     if rank == 0:
         extra["kernels"] = kernels
         extra["timed_region_s"] = round(dt, 4)
+        extra["gpu_idle"] = gpu_idle
+        extra["gpu_idle_ms_per_step"] = gpu_idle["idle_ms_per_step"] if gpu_idle else None
         try:
             if args.no_extras:
                 raise RuntimeError("skipped (--no-extras)")

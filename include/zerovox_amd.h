@@ -120,7 +120,7 @@ zv_status zv_synthesize(zv_model *m, const int32_t *ids, const int32_t *puncts, 
  * through the three stages as ONE launch per kernel: tensors are row-concatenated over the group and a segment table in
  * HBM tells every kernel where each utterance begins and ends, so the launches have many rounds of workgroups and the
  * whole group — input upload included — is one hipGraph (captured once per capacity bucket when graph mode is on).  For a
- * large group the graph ends before the last vocoder stage's residual blocks: those and the output conv run in four
+ * large group the graph ends before the last vocoder stage's residual blocks: those and the output conv run in
  * utterance sub-groups and a finished sub-group's waveforms are copied to the host (second stream) and into wav[] while
  * the next one computes; wav[u] is complete when the call returns, as before.
  * BASELINE.json configs[3]/[4]; with several GPUs the caller shards the list (one model per GPU, no collective). */
@@ -134,12 +134,19 @@ zv_status zv_synthesize_batch(zv_model *m, uint32_t n_utt, const int32_t *const 
  * activation arena and a pinned staging block) and returns; _end waits for that batch and fills wav[] / n_frames[], which
  * — like T[] and the pointer arrays' targets — must stay valid until then.  While one lane's last kernels and downloads
  * run, the next lane's upload and first kernels already do.  Results are those of zv_synthesize_batch, bit for bit.
+ * Two batches in flight (begin k, end k - 1) keep the GPU busy all the time (zv_batch_timeline: no gap); more lanes work
+ * and buy nothing.
  * Every other entry point may be called in between (they use lane 0's stream: not while lane 0 has a batch in flight). */
 #define ZV_BATCH_LANES 4
 zv_status zv_synthesize_batch_begin(zv_model *m, uint32_t lane, uint32_t n_utt, const int32_t *const *ids,
                                     const int32_t *const *puncts, const float *const *styles, const uint32_t *n_phonemes,
                                     const uint32_t *T, float *const *wav, uint32_t *n_frames);
 zv_status zv_synthesize_batch_end(zv_model *m, uint32_t lane);
+/* When the last batches ran on the GPU (measurement): for the most recent min(cap, batches begun, 64) batches, oldest first,
+ * the times in ms — relative to the first one's start — at which the batch's first operation started and its last kernel
+ * ended (HIP events on the lanes' streams; waits for every lane first).  The gaps of the union of [start, end] are the time the
+ * GPU had no batch to work on: bench.py reports them as extra.gpu_idle_ms_per_step. */
+zv_status zv_batch_timeline(zv_model *m, uint32_t cap, double *start_ms, double *end_ms, uint32_t *n);
 
 /* longest single utterance in frames (buffer descriptors address one utterance with 32-bit byte offsets; at most
  * 32768 frames = 7.4 min of audio).  Longer T returns ZV_ERR_ARG; zv_vocode_stream has no such limit on the total. */
@@ -150,7 +157,10 @@ uint32_t  zv_max_frames(const zv_model *m);
 void      zv_demo_utterance(const int32_t **ids, const int32_t **puncts, const float **style, uint32_t *n_phonemes,
                             uint32_t *style_len);
 
-/* ---- device-resident variants (inputs already in HBM; enqueue on the model's stream) ------- */
+/* ---- device-resident variants (inputs already in HBM) ------------------------------------------
+ * zv_vocode_device / zv_decode_device enqueue on LANE 0's stream and return; zv_memcpy_h2d / _d2h copy on that same stream
+ * (so they are ordered with those calls whatever lane a batch was last begun on) and wait for the copy; zv_synchronize waits
+ * for EVERY lane.  zv_profile_begin / _end bracket work of the synchronous entry points (lane 0). */
 void     *zv_device_alloc(zv_model *m, size_t bytes);
 void      zv_device_free(zv_model *m, void *p);
 zv_status zv_memcpy_h2d(zv_model *m, void *dst, const void *src, size_t bytes);
@@ -200,12 +210,15 @@ typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLO
 zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out);
 
 /* ---- test / measurement switches (none is needed in production; no reference counterpart: the reference's only run-time
- * switch is the thread count, src/zerovox.cpp:86-91).  The library reads the environment ONCE, when it is loaded (variables
- * named like the switches, so that a shell script can A/B a run); afterwards a switch changes only through this call.
- * Schedule switches (ZV_NO_FUSE, ZV_NO_TRIPLE, ZV_FUSE256, ZV_NO_MERGE, ZV_TAIL_GROUPS, ZV_VOC_GROUP) are sampled when a
- * model is loaded, kernel-regime switches at every launch.  name == NULL resets every switch to its built-in default.
- * ZV_ERR_ARG for an unknown name.  The list: zerovox.cpp_amd/csrc/knobs.h. */
+ * switch is the thread count, src/zerovox.cpp:86-91).  The shipped library never reads the environment: a switch changes only
+ * through this call (the Python test binding forwards ZV_* environment variables through it so that a shell script can A/B a
+ * run).  Schedule switches (ZV_NO_FUSE, ZV_NO_TRIPLE, ZV_FUSE256, ZV_NO_MERGE, ZV_TAIL_GROUPS) are sampled when a model is
+ * loaded, kernel-regime switches at every launch; a captured hipGraph replays the regime it was captured in, so every call of
+ * zv_debug_set makes the models capture anew.  name == NULL resets every switch to its built-in default.  ZV_ERR_ARG for an
+ * unknown name.  The list: zerovox.cpp_amd/csrc/knobs.h (timing-only ablation switches that give wrong results exist only in
+ * diagnostic builds, -DZV_DIAG).  zv_debug_get reads a switch. */
 zv_status zv_debug_set(const char *name, int value);
+zv_status zv_debug_get(const char *name, int *value);
 
 /* ---- GGUF inspection without a device (loader half of the boundary; used by the CPU test-suite) ----
  * Parses the file exactly as zv_model_load does and reports the counts; *max_seq_len receives the

@@ -12,7 +12,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'zv::' not in n: continue
-    key = (n.split('(')[0].replace('void zv::',''), r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'], r['LDS_Block_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'])
+    key = (n.split('(')[0].replace('void ','').replace('zv::',''), r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'], r['LDS_Block_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'])
     a = agg.setdefault(key, [0,0]); a[0]+=1; a[1]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
 tot = sum(t for _,t in agg.values())
 for k,(n,t) in agg.items():

@@ -11,6 +11,6 @@ for ln in sys.stdin:
     m = re.search(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass', ln)
     if m and cur: rows[cur][m.group(1).strip()] = m.group(2)
 for k, v in rows.items():
-    name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().replace('void zv::','')
+    name = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip().replace('void ','').replace('zv::','')
     if pat in name: print(f\"{name.split('(')[0]:58s} vgpr {v.get('VGPRs','?'):>4s} agpr {v.get('AGPRs','?'):>4s} sgpr {v.get('TotalSGPRs','?'):>4s} scratch {v.get('ScratchSize','?'):>4s} spill {v.get('VGPRs Spill','?'):>3s} occ {v.get('Occupancy','?')}\")
 " "$2"

@@ -11,7 +11,7 @@ rows = []
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'zv::' not in n: continue
-    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n.split('(')[0].replace('void zv::','')[:40], r.get('Queue_Id','?')))
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n.split('(')[0].replace('void ','').replace('zv::','')[:40], r.get('Queue_Id','?')))
 rows.sort()
 # keep the last 60 % (steady state)
 t0 = rows[int(len(rows)*0.4)][0]
@@ -43,7 +43,7 @@ f = glob.glob('/tmp/zvovl/**/*kernel_trace.csv', recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
-    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n.split('(')[0].replace('void zv::','')[:34], r.get('Queue_Id','?')))
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n.split('(')[0].replace('void ','').replace('zv::','')[:34], r.get('Queue_Id','?')))
 rows.sort()
 t0 = rows[int(len(rows)*0.4)][0]
 rows = [r for r in rows if r[0] >= t0]

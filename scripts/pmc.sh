@@ -5,7 +5,7 @@ CNT="$1"; shift
 rm -rf /tmp/zvpmc && mkdir -p /tmp/zvpmc
 env "$@" rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/zvpmc -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-graph --no-extras --no-pipeline > /tmp/zvpmc/bench.json 2>/tmp/zvpmc/err.txt
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re
 fs = glob.glob('/tmp/zvpmc/**/*counter_collection.csv', recursive=True)
 if not fs:
     print(open('/tmp/zvpmc/err.txt').read()[-2000:]); raise SystemExit
@@ -13,7 +13,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(fs[0])):
     n = r['Kernel_Name']
     if 'zv::' not in n: continue
-    key = (n.split('(')[0].replace('void zv::',''), r['Grid_Size'], r.get('LDS_Block_Size',''))
+    key = (re.sub(r'^(void )?zv::', '', n.split('(')[0]), r['Grid_Size'], r.get('LDS_Block_Size',''))
     d = agg.setdefault(key, collections.OrderedDict())
     c = d.setdefault(r['Counter_Name'], [0, 0.0]); c[0]+=1; c[1]+=float(r['Counter_Value'])
 for k, d in agg.items():

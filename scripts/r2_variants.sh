@@ -13,7 +13,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'zv::' not in n: continue
-    key = (n.split('(')[0].replace('void zv::',''), r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
+    key = (n.split('(')[0].replace('void ','').replace('zv::',''), r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
     a = agg.setdefault(key, [0,0]); a[0]+=1; a[1]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
 tot = sum(t for _,t in agg.values())
 for k,(n,t) in agg.items():

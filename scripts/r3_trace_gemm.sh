@@ -10,7 +10,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last pass: from the last embed kernel on
 last = max(i for i, r in enumerate(rows) if 'embed_kernel' in r['Kernel_Name'])
 for r in rows[last:]:
-    n = r['Kernel_Name'].split('(')[0].replace('void zv::', '')
+    n = r['Kernel_Name'].split('(')[0].replace('void ','').replace('zv::','')
     if 'conv' in n or 'norm_act' in n:
         print(f"{n[:44]:44s} grid=({r['Grid_Size_X']},{r['Grid_Size_Y']},{r['Grid_Size_Z']}) us={(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1000:.1f}")
 PY

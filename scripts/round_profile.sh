@@ -14,8 +14,8 @@ cp /tmp/zvprof/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null || t
   echo "# WRITE_SIZE / L2 pass (ZV_TAIL_GROUPS=0)"; bash scripts/pmc.sh "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ZV_TAIL_GROUPS=0 ) > $OUT/${TAG}_pmc.txt 2>&1
 python scripts/chain.py > $OUT/${TAG}_full_chain.txt 2>&1
 python scripts/traffic.py $OUT/${TAG}_pmc.txt $OUT/${TAG}_kernel_trace_summary.txt $TAG > $OUT/${TAG}_resblock_traffic.json
-# bench.py quotes profiles/r03_resblock_traffic.json while its kernel_src_sha256 matches the source: re-run the bench with it in place
-cp $OUT/${TAG}_resblock_traffic.json profiles/r03_resblock_traffic.json
+# bench.py quotes profiles/r04_resblock_traffic.json while its kernel_src_sha256 matches the source: re-run the bench with it in place
+cp $OUT/${TAG}_resblock_traffic.json profiles/r04_resblock_traffic.json
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 bash scripts/r3_trace_gemm.sh A=1 > $OUT/${TAG}_one_pass_dispatches.txt 2>&1
 cat $OUT/${TAG}_bench.json | head -c 1500; echo; cat $OUT/${TAG}_resblock_traffic.json

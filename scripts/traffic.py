@@ -16,12 +16,18 @@ def stage_of(key):
     if key.startswith("resblock_pair_kernel<128"): return "s1"
     if key.startswith(("resblock_pair64_kernel", "resblock_pair_kernel<64", "resblock_block64_kernel")): return "s2"
     return "s3"
+def norm(ln):
+    """kernel names as the profiler prints them: templates as `void zv::name<...>`, plain kernels as `zv::name` — one form here"""
+    return re.sub(r"^(void )?(zv::)?", "", ln)
+
+
 fetch, write, n = {}, {}, {}
 sect = None
 for ln in open(pmc):
     if ln.startswith("#"):
         sect = ln
         continue
+    ln = norm(ln)
     if not ln.startswith(fam):
         continue
     key = ln.split(" grid ")[0] + " grid " + ln.split(" grid ")[1].split()[0]
@@ -34,18 +40,32 @@ for ln in open(pmc):
         write[key] = float(m.group(1)) * 1024
 dur = {}
 for ln in open(trace):
+    ln = norm(ln)
     if not ln.startswith(fam):
         continue
     name = ln.split("grid=")[0].strip()
     g = re.search(r"grid=\((\d+),(\d+),(\d+)\)", ln)
     key = "%s grid %d" % (name, int(g.group(1)) * int(g.group(2)) * int(g.group(3)))
     dur[key] = (int(re.search(r"calls=(\d+)", ln).group(1)), float(re.search(r"avg_us=([0-9.]+)", ln).group(1)))
+# the evidence chain must close: every family configuration of the PMC passes has a FETCH row, a WRITE row and a duration in the
+# kernel trace, and a family kernel of the trace without PMC rows is only the same kernel on another grid (the timed region's
+# utterance groups; the PMC passes run whole-batch launches).  Anything else is a parsing hole: stop, do not average around it.
+problems = []
+for k in sorted(set(fetch) | set(write)):
+    if k not in fetch: problems.append("no FETCH_SIZE row for " + k)
+    if k not in write: problems.append("no WRITE_SIZE row for " + k)
+    if k not in dur: problems.append("no kernel-trace duration for " + k)
+pmc_names = {k.split(" grid ")[0] for k in fetch}
+for k in dur:
+    if k not in fetch and k.split(" grid ")[0] not in pmc_names:
+        problems.append("family kernel of the trace has no PMC row on any grid: " + k)
+if not fetch: problems.append("no ResBlock family rows found in " + pmc)
+if problems:
+    sys.exit("traffic.py: " + "; ".join(problems))
 tot_b = tot_n = tot_us = 0.0
 per = {}
 for k in fetch:
-    if k not in write:
-        continue
-    calls, us = dur.get(k, (n[k], 0.0))
+    calls, us = dur[k]
     b = fetch[k] + write[k]
     per[k] = {"hbm_bytes_per_launch": b, "avg_launch_us": us, "GBps": round(b / (us * 1e-6) / 1e9, 1) if us else None}
     tot_b += b * n[k]

@@ -332,3 +332,38 @@ def test_nothing_depends_on_fresh_arena_contents(models, ckpt, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(np.load(out), wav)
+
+
+def test_batch_regime_kernels_do_not_depend_on_fresh_arena_contents(ckpt, tmp_path):
+    """the same poison test with the kernels only batches pick forced on (conv_gemm_kernel reads "finite neighbours" past Cin_p
+    against zero weights, the operand passes convert whole capacities, xr16 / the f16 c0 are arena tenants of their own): a NaN
+    pattern in a row nobody wrote, times a zero weight, would be a NaN — the NaN-filled run must give the zero-filled run's bits"""
+    import subprocess
+    import sys
+    from zerovox_cpp_amd import capi, synth
+    regime = dict(ZV_CONV_GEMM=2, ZV_UP_GEMM=2, ZV_CONV_STREAM=2, ZV_BLOCK64=-3, ZV_DEC_PREPASS=1, ZV_PAIR64_RING=2, ZV_TRIPLE_V2=3,
+                  ZV_FUSE256=1, ZV_MERGE_ALWAYS=1)
+    path, g, _ = ckpt("medium")
+    ids, puncts, style = synth.encoder_inputs(g, 78, 24)
+    T = 96
+    with capi.switches(**regime):
+        m = capi.Model(path, 0)
+        wav, nf = m.synthesize(ids, puncts, style, T)
+        m.close()
+    assert np.isfinite(wav).all()
+    out = tmp_path / "poison_batch.npy"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from __graft_entry__ import load_package\nload_package()\n"
+        "from zerovox_cpp_amd import capi, synth\n"
+        f"m = capi.Model({path!r}, 0)\n"
+        "ids, puncts, style = synth.encoder_inputs(synth.MEDIUM, 78, 24)\n"
+        f"b = m.synthesize_batch([(ids, puncts, style, {T})] * 3)\n"
+        f"w, nf = m.synthesize(ids, puncts, style, {T})\n"
+        "assert all(np.array_equal(x[0], w) and x[1] == nf for x in b)\n"
+        f"np.save({str(out)!r}, w)\n")
+    env = dict(os.environ, ZV_ARENA_FILL="255", **{k: str(v) for k, v in regime.items()})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out), wav)

@@ -73,10 +73,7 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
     for v in (0, 1):
         with capi.switches(ZV_DEC_PREPASS=v):
             assert np.array_equal(model.decode(hid, style), mel), v
-        # the batch form of the wide convs (loader waves + double-buffered tile) forced onto one utterance, and the
-        # single-utterance MFMA loop switched off: same chain per output element, same bits
-        with capi.switches(ZV_DEC_PREPASS=v, ZV_CONV_LW=2):
-            assert np.array_equal(model.decode(hid, style), mel), ("loader waves", v)
+        # the single-utterance MFMA loop switched off: same chain per output element, same bits
         with capi.switches(ZV_DEC_PREPASS=v, ZV_CONV_SINGLE=0):
             assert np.array_equal(model.decode(hid, style), mel), ("no single loop", v)
     # the batches' 256 x 256-tile GEMM form of the wide convs (both operands through LDS by LDS-DMA, taps folded into the K loop)
@@ -168,7 +165,7 @@ def test_batch_regime_kernels_vs_reference_golden(ckpt, fixture):
     z = np.load(os.path.join(GOLD, fixture))
     T, s = int(z["T"]), int(z["stride"])
     mel = synth.vocoder_mel(g, tensors, int(z["seed_mel"]), T)
-    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=2, ZV_PAIR64_RING=2, ZV_TRIPLE_CFG=2512, ZV_MERGE_ALWAYS=1, ZV_CONV_LW=2, ZV_PAIR_INTERLEAVE=2, ZV_BLOCK_SUM=2, ZV_UP_GEMM=2, ZV_CONV_GEMM=2, ZV_CONV_STREAM=2, ZV_BLOCK64=-11, ZV_BLOCK64_ALL=1):
+    with capi.switches(ZV_FUSE256=1, ZV_TRIPLE_V2=3, ZV_PAIR64_RING=2, ZV_MERGE_ALWAYS=1, ZV_UP_GEMM=2, ZV_CONV_GEMM=2, ZV_CONV_STREAM=2, ZV_BLOCK64=-11):
         m = capi.Model(path, 0)
         wav = m.vocode(mel)
         m.close()
@@ -231,23 +228,16 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       ("fuse256_merge_mt3", {"ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1", "ZV_PAIR_MT": "3"}),
                       ("pair64_ring_merge", {"ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1"}),
                       ("single_loop_everywhere", {"ZV_CONV_SINGLE": "2"}), ("no_single_loop", {"ZV_CONV_SINGLE": "0"}),
-                      ("loader_waves", {"ZV_CONV_LW": "2"}),
                       ("block_v1", {"ZV_TRIPLE_V2": "0"}), ("block_v2", {"ZV_TRIPLE_V2": "2"}),
-                      ("block_v2_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512"}),
-                      ("block_v2_512_mt4", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "4512"}),
+                      ("block_v2_512", {"ZV_TRIPLE_V2": "3"}), ("block_v2_512_one_weight_buffer", {"ZV_TRIPLE_V2": "3", "ZV_TRIPLE_DB": "0"}),
+                      ("block_v2_not_interleaved", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_INTERLEAVE": "0"}),
                       ("pair64_ring", {"ZV_PAIR64_RING": "2"}), ("pair64_ring_no_merge", {"ZV_PAIR64_RING": "2", "ZV_NO_MERGE": "1"}),
                       ("pair64_no_ring", {"ZV_PAIR64_RING": "0"}),
                       ("upsample_gemm", {"ZV_UP_GEMM": "2", "ZV_CONV_GEMM": "2"}), ("upsample_no_gemm", {"ZV_UP_GEMM": "0"}),
-                      ("block64_3_whole", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1", "ZV_BLOCK64_ALL": "1"}), ("block64_3_two_pairs", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1", "ZV_BLOCK64_ALL": "0"}),
+                      ("block64_3_merge", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2", "ZV_MERGE_ALWAYS": "1"}),
                       ("block64_3_no_merge", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2"}), ("block64_11", {"ZV_BLOCK64": "-11", "ZV_PAIR64_RING": "2"}),
                       ("no_block64", {"ZV_BLOCK64": "0", "ZV_PAIR64_RING": "2"}),
-                      ("upsample_stream", {"ZV_CONV_STREAM": "2"}), ("upsample_no_stream", {"ZV_CONV_STREAM": "0"}),
-                      ("block_sum", {"ZV_TRIPLE_V2": "2", "ZV_BLOCK_SUM": "2"}),
-                      ("block_sum_512", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512", "ZV_BLOCK_SUM": "2"}),
-                      ("block_no_sum", {"ZV_TRIPLE_V2": "2", "ZV_TRIPLE_CFG": "2512", "ZV_BLOCK_SUM": "0"}),
-                      ("branches_interleaved", {"ZV_PAIR_INTERLEAVE": "2", "ZV_FUSE256": "1"}),
-                      ("branches_interleaved_ring", {"ZV_PAIR_INTERLEAVE": "2", "ZV_PAIR64_RING": "2"}),
-                      ("branches_not_interleaved", {"ZV_PAIR_INTERLEAVE": "0"})):
+                      ("upsample_stream", {"ZV_CONV_STREAM": "2"}), ("upsample_no_stream", {"ZV_CONV_STREAM": "0"})):
         with capi.switches(**{k: int(v) for k, v in env.items()}):      # some switches are sampled when the model is built, some at every launch
             m = capi.Model(path, 0)
             outs[name] = m.vocode(mel)

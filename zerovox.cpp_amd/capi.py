@@ -20,6 +20,7 @@ SYMBOLS = [
     "zv_encode", "zv_encode_taps", "zv_decode", "zv_vocode", "zv_synthesize", "zv_synthesize_batch", "zv_synthesize_batch_begin", "zv_synthesize_batch_end", "zv_device_alloc", "zv_device_free",
     "zv_memcpy_h2d", "zv_memcpy_d2h", "zv_vocode_device", "zv_vocode_stream", "zv_vocoder_halo_frames", "zv_decode_device", "zv_synchronize", "zv_set_graph_mode",
     "zv_profile_begin", "zv_profile_end", "zv_write_wav", "zv_gguf_inspect", "zv_max_frames", "zv_demo_utterance", "zv_debug_layer", "zv_debug_set",
+    "zv_debug_get", "zv_batch_timeline",
 ]
 
 
@@ -71,6 +72,8 @@ def load_library(path: Optional[str] = None):
     lib.zv_encode_taps.argtypes = [vp, i32p, i32p, fp, u32, u32, u32, fp, C.POINTER(u32), fp, fp, fp, fp, i32p, i32p]
     lib.zv_debug_layer.argtypes = [vp, C.c_int, C.c_int, fp, u32, fp, fp]
     lib.zv_debug_set.argtypes = [C.c_char_p, C.c_int]
+    lib.zv_debug_get.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.zv_batch_timeline.argtypes = [vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u32)]
     lib.zv_max_frames.argtypes = [vp]
     lib.zv_max_frames.restype = u32
     lib.zv_demo_utterance.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
@@ -103,7 +106,24 @@ def load_library(path: Optional[str] = None):
                                     C.POINTER(C.c_int64)]
     if path is None:
         _lib = lib
+    _forward_env_switches(lib)
     return lib
+
+
+def _forward_env_switches(lib):
+    """The shipped library never reads the environment.  This test / bench binding forwards ZV_* variables that name a switch
+    (csrc/knobs.h) through zv_debug_set, once per load, so that `ZV_PAIR_MT=4 python bench.py` still A/Bs a run; variables that
+    name no switch of this build (ZV_BENCH_LANES, a diagnostic switch on a shipped build ...) are left alone."""
+    for k, v in sorted(os.environ.items()):
+        if not k.startswith("ZV_"):
+            continue
+        try:
+            val = int(v)
+        except ValueError:
+            continue
+        cur = C.c_int(0)
+        if lib.zv_debug_get(k.encode(), C.byref(cur)) == 0:
+            lib.zv_debug_set(k.encode(), val)
 
 
 def _ptr(a):
@@ -118,20 +138,34 @@ def debug_set(name: Optional[str], value: int = 0):
         raise ZvError(st, lib.zv_last_error().decode())
 
 
+def debug_get(name: str) -> int:
+    lib = load_library()
+    v = C.c_int(0)
+    st = lib.zv_debug_get(name.encode(), C.byref(v))
+    if st != 0:
+        raise ZvError(st, lib.zv_last_error().decode())
+    return int(v.value)
+
+
 class switches:
     """`with capi.switches(ZV_NO_FUSE=1, ...):` — the switches hold inside the block (schedule switches are sampled by
-    Model(), kernel-regime switches at every launch) and every switch is back at its default afterwards"""
+    Model(), kernel-regime switches at every launch; captured graphs are re-captured) and go back to the values they had
+    before it afterwards (not to their built-in defaults: a value set for the whole run, e.g. ZV_ARENA_FILL=255, survives,
+    and blocks nest)"""
 
     def __init__(self, **kw):
         self.kw = kw
+        self.saved = {}
 
     def __enter__(self):
         for k, v in self.kw.items():
+            self.saved[k] = debug_get(k)
             debug_set(k, int(v))
         return self
 
     def __exit__(self, *exc):
-        debug_set(None)
+        for k, v in self.saved.items():
+            debug_set(k, v)
         return False
 
 
@@ -289,6 +323,12 @@ class Model:
 
     def reserve(self, max_phonemes: int, max_frames: int):
         self._chk(self.lib.zv_model_reserve(self.h, max_phonemes, max_frames))
+
+    def batch_timeline(self, cap: int = 64):
+        """zv_batch_timeline: [(start_ms, end_ms)] of the most recent batches, oldest first"""
+        a, b, n = (C.c_double * cap)(), (C.c_double * cap)(), C.c_uint32(0)
+        self._chk(self.lib.zv_batch_timeline(self.h, cap, a, b, C.byref(n)))
+        return [(a[i], b[i]) for i in range(n.value)]
 
     def profile_begin(self):
         self._chk(self.lib.zv_profile_begin(self.h))

@@ -20,6 +20,7 @@ struct zv_model
 };
 
 static void free_pending(zv_model *m);
+static void lane0_select(zv_model *m);   // selects lane 0 without the busy check (copies, waits, profiling)
 static void use_lane0(zv_model *m);      // selects lane 0 (the lane of every synchronous entry point); fails when lane 0 has a batch in flight
 
 static thread_local std::string g_last_error;
@@ -360,6 +361,11 @@ static void free_pending(zv_model *m)
     delete[] m->pending;
     m->pending = nullptr;
 }
+static void lane0_select(zv_model *m)
+{
+    if (hipSetDevice(m->m->device) != hipSuccess) zv::fail(ZV_ERR_DEVICE, "hipSetDevice(%d) failed", m->m->device);
+    m->m->select_lane(0);
+}
 static void use_lane0(zv_model *m)
 {
     // the synchronous and device-resident entry points run on lane 0's stream, arena and I/O block whatever lane was
@@ -450,21 +456,17 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
         hipStream_t cs = M.copy_stream();
         pb.gb.assign(G + 1, n_utt);
         pb.gb[0] = 0;
-        // Batches in flight on different lanes share the GPU kernel by kernel; left alone they advance side by side and end
-        // together, and the card idles while the host turns both around (kernel trace: 1.3-2.0 ms without a kernel after every
-        // pair of batches).  ZV_LANE_ORDER = 1: a batch's head (everything up to the last vocoder stage) starts when the batch
-        // before it (on another lane) has finished ITS head — the batches end a tail apart; 2: when it has finished altogether.
-        const int order = zv::knob(zv::ZV_LANE_ORDER);
-        if (order && M.order_last_lane() >= 0 && M.order_last_lane() != lane)
-            ZV_HIP(hipStreamWaitEvent(M.stream, M.order_event(M.order_last_lane(), order == 2 ? 1 : 0), 0));
+        // Batches in flight on different lanes share the GPU kernel by kernel (worth 1.4 ms per batch: the latency-bound encoder /
+        // decoder launches of one fill the other's vocoder).  Every batch owns a (start, done) pair of timing events on its lane's
+        // stream — zv_batch_timeline reports from them when the GPU had no batch to work on.  (Round 4 measured that number
+        // without a profiler: 0.00 ms per step with two batches in flight; a device-side limit of two concurrent batches with a
+        // third queued behind them, built to close gaps a kernel trace had shown, changed nothing and was removed again.)
+        const uint64_t seq = M.next_batch_seq();
+        ZV_HIP(hipEventRecord(M.batch_event(seq, 0), M.stream));
         if (G <= 1)
         {
             M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in);
-            if (order)
-            {
-                ZV_HIP(hipEventRecord(M.order_event(lane, 0), M.stream));
-                ZV_HIP(hipEventRecord(M.order_event(lane, 1), M.stream));
-            }
+            ZV_HIP(hipEventRecord(M.batch_event(seq, 1), M.stream));
             ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
             ZV_HIP(hipMemcpyAsync(h_wav, d_wav, wav_bytes, hipMemcpyDeviceToHost, M.stream));
             ZV_HIP(hipEventRecord(M.tail_event(1), M.stream));
@@ -472,7 +474,6 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
         else
         {
             M.chain_dev(bt, d_ids, d_pun, d_sty, d_hid, d_mel, d_wav, d_nf, pin, d_in, b_in, 1);
-            if (order) ZV_HIP(hipEventRecord(M.order_event(lane, 0), M.stream));
             ZV_HIP(hipMemcpyAsync(h_nf, d_nf, (size_t)bt.nseg * 4, hipMemcpyDeviceToHost, M.stream));
             for (int g = 1; g < G; g++)               // contiguous groups of about wav_bytes / G each
             {
@@ -490,9 +491,8 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
                 ZV_HIP(hipMemcpyAsync(h_wav + o0, (const char *)d_wav + o0, o1 - o0, hipMemcpyDeviceToHost, cs));
                 ZV_HIP(hipEventRecord(M.tail_event(2 * g + 1), cs));
             }
-            if (order) ZV_HIP(hipEventRecord(M.order_event(lane, 1), M.stream));
+            ZV_HIP(hipEventRecord(M.batch_event(seq, 1), M.stream));
         }
-        if (order) M.set_order_last_lane(lane);
     }
     catch (...)
     {
@@ -616,6 +616,30 @@ zv_status zv_synthesize_batch_end(zv_model *m, uint32_t lane)
     });
 }
 
+zv_status zv_batch_timeline(zv_model *m, uint32_t cap, double *start_ms, double *end_ms, uint32_t *n)
+{
+    return guarded([&] {
+        ZV_NEED(m && start_ms && end_ms && n, "null argument");
+        Model &M = *m->m;
+        ZV_HIP(hipSetDevice(M.device));
+        M.sync_all_lanes();
+        const uint64_t total = M.batch_seq();
+        const uint64_t cnt = std::min<uint64_t>(std::min<uint64_t>(cap, total), (uint64_t)Model::BATCH_RING);
+        *n = (uint32_t)cnt;
+        if (!cnt) return;
+        const uint64_t first = total - cnt;
+        hipEvent_t base = M.batch_event(first, 0);
+        for (uint64_t i = 0; i < cnt; i++)
+        {
+            float a = 0.f, b = 0.f;
+            ZV_HIP(hipEventElapsedTime(&a, base, M.batch_event(first + i, 0)));
+            ZV_HIP(hipEventElapsedTime(&b, base, M.batch_event(first + i, 1)));
+            start_ms[i] = a;
+            end_ms[i] = b;
+        }
+    });
+}
+
 // ---- one layer at a time (tests: teacher-forced per-layer parity) -------------------------------------------------
 
 zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out)
@@ -723,6 +747,14 @@ zv_status zv_debug_set(const char *name, int value)
     });
 }
 
+zv_status zv_debug_get(const char *name, int *value)
+{
+    return guarded([&] {
+        ZV_NEED(name && value, "null argument");
+        if (!zv::knob_get(name, value)) zv::fail(ZV_ERR_ARG, "unknown switch '%s'", name);
+    });
+}
+
 // ---- device-resident entry points ---------------------------------------------------------------
 
 void *zv_device_alloc(zv_model *m, size_t bytes)
@@ -742,7 +774,7 @@ void zv_device_free(zv_model *m, void *p)
 {
     if (!m || !p) return;
     hipSetDevice(m->m->device);
-    hipStreamSynchronize(m->m->stream);
+    try { m->m->sync_all_lanes(); } catch (...) {}
     hipFree(p);
 }
 
@@ -750,7 +782,9 @@ zv_status zv_memcpy_h2d(zv_model *m, void *dst, const void *src, size_t bytes)
 {
     return guarded([&] {
         ZV_NEED(m && dst && src, "null argument");
-        ZV_HIP(hipSetDevice(m->m->device));
+        // lane 0's stream, the one zv_vocode_device / zv_decode_device run on, whatever lane was touched last (the lanes' streams
+        // are not ordered with each other); no busy check: the copy only queues behind what lane 0 already holds
+        lane0_select(m);
         ZV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->m->stream));
         m->m->sync();
     });
@@ -760,7 +794,7 @@ zv_status zv_memcpy_d2h(zv_model *m, void *dst, const void *src, size_t bytes)
 {
     return guarded([&] {
         ZV_NEED(m && dst && src, "null argument");
-        ZV_HIP(hipSetDevice(m->m->device));
+        lane0_select(m);
         ZV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->m->stream));
         m->m->sync();
     });
@@ -791,7 +825,9 @@ zv_status zv_synchronize(zv_model *m)
     return guarded([&] {
         ZV_NEED(m, "null model");
         ZV_HIP(hipSetDevice(m->m->device));
-        m->m->sync();
+        // every lane: whatever entry point enqueued it, the work is done when this returns (a batch begun with
+        // zv_synthesize_batch_begin still needs its _end: that is where its waveforms leave the staging block)
+        m->m->sync_all_lanes();
     });
 }
 
@@ -809,7 +845,7 @@ zv_status zv_profile_begin(zv_model *m)
 {
     return guarded([&] {
         ZV_NEED(m, "null model");
-        ZV_HIP(hipSetDevice(m->m->device));
+        lane0_select(m);                      // the synchronous entry points, which are what gets profiled, run on lane 0
         m->m->sync();
         m->m->prof_clear();
         m->m->profiling = true;
@@ -821,7 +857,7 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
     return guarded([&] {
         ZV_NEED(m && n, "null argument");
         Model &M = *m->m;
-        ZV_HIP(hipSetDevice(M.device));
+        lane0_select(m);
         M.sync();
         M.profiling = false;
         std::map<std::string, zv_kernel_stat> agg;

@@ -237,7 +237,7 @@ __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *sme
 }
 
 // PRO_RAW_F16 in 16-byte pieces (8 channels) for NTH threads: every load of a round is in flight before the first is
-// stored (U x 16 B per thread), so a tile of <= NTH * U pieces costs one round trip.  Used by the loader waves.
+// stored (U x 16 B per thread), so a tile of <= NTH * U pieces costs one round trip.
 template <int U, int NTH>
 __device__ __forceinline__ void stage_raw16(const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid)
 {
@@ -267,16 +267,6 @@ __device__ __forceinline__ void stage_raw16(const StageSrc &J, char *smem, int R
         for (int u = 0; u < U; u++)
             if (live[u]) *(uint4 *)(smem + lofs[u]) = inr[u] ? v[u] : make_uint4(0, 0, 0, 0);
     }
-}
-
-// a tile staged by NTH of the workgroup's threads (tid = 0 .. NTH-1)
-template <int U, int NTH>
-__device__ __forceinline__ void stage_any(int pro, const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid)
-{
-    if (pro == PRO_RAW_F16 && (ck & 7) == 0)
-        stage_raw16<(U > 8 ? U : 8), NTH>(J, smem, RS, c0, ck, row_t0, rows, tid);
-    else
-        stage_tile<(U > 4 ? 4 : U), NTH>(pro, J, smem, RS, c0, ck, row_t0, rows, tid);
 }
 
 // ---- compute: S = K * nkc MFMA steps over one staged chunk.  A fragments are double-buffered in registers
@@ -648,13 +638,10 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 // (Measured dead end, round 2: the staged tile double-buffered in LDS and filled by LDS-DMA while the MFMA loop of the
 // previous chunk runs.  hipcc answers an LDS-DMA in flight with vmcnt(0) waits on the B-fragment stream of the MFMA
 // loop — the counted waits that keep eight fragments in flight are gone — and the wide decoder convs ran 3 % slower.)
-// LW > 0 (multi-chunk convs of a batch: the wide decoder / encoder convs): LW extra "loader" waves stage chunk c + 1 into
-// the other half of a double-buffered LDS tile while the four compute waves run the MFMA loop of chunk c — one barrier per
-// chunk, the compute waves issue no vector-memory instruction besides their weight-fragment stream (whose counted waits
-// therefore survive), and the staging round trip that phase stamps showed as 5.5-6.2 us in front of every 6.4-7.7 us
-// MFMA loop (profiles/r02_v2_stamps_decoder_conv.txt) disappears behind it.  Same chain per output element: same bits.
-template <int MT, int WN, int NT, bool SINGLE = false, int LW = 0>
-__global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC == 3)) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
+// (Measured dead end, round 3: two extra "loader" waves staging chunk c + 1 into a second LDS tile under the MFMA loop of chunk c:
+// decoder convs 311 -> 378 us; removed in round 4.)
+template <int MT, int WN, int NT, bool SINGLE = false>
+__global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
@@ -673,8 +660,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = LW > 0 && wave >= 4;
-    const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, Cout_p = J.Cout_p;
     const int nicb = Cin_p >> 4;
@@ -684,7 +670,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     const int nt_span = ntiles - jobs.nt_begin;     // (tiles before nt_begin belong to conv_gemm_kernel)
     const int gt0 = jobs.nt_begin + (int)((long)blockIdx.y * nt_span / gridDim.y), gt1 = jobs.nt_begin + (int)((long)(blockIdx.y + 1) * nt_span / gridDim.y);
     const int nt0 = gt0 + wn * NT;
-    const bool n_ok = nt0 < gt1 && !is_loader;
+    const bool n_ok = nt0 < gt1;
     // a wave whose second tile does not exist computes the tile before it twice and stores it once
     const int ntl = nt0 + NT <= gt1 ? nt0 : (gt1 - NT > 0 ? gt1 - NT : 0);
     const int rows = BM + (K - 1) * dil;
@@ -725,55 +711,11 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     int stamp_k = 1;
 #endif
     ZV_STAMP(0)
-    if constexpr (LW > 0)
-    {
-        // tile buffers 0 / 1 alternate per chunk; chunk 0 is staged by every thread of the workgroup
-        const int tile_bytes = round_up((rows + dil) * RS, 16);
-        const int nchunk = (Cin_p + J.ck - 1) / J.ck;
-        if (!(J.dbg & 1))
-        {
-            const int ck0 = Cin_p < J.ck ? Cin_p : J.ck;
-            stage_any<8, 256 + 64 * LW>(J.pro, S, smem, RS, 0, ck0, m0 - J.pad, rows, tid);
-        }
-        __syncthreads();
-        for (int ic = 0; ic < nchunk; ic++)
-        {
-            const int c0 = ic * J.ck;
-            const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-            if (is_loader)
-            {
-                if (ic + 1 < nchunk && !(J.dbg & 1))
-                {
-                    const int c1 = c0 + J.ck;
-                    const int ck1 = (Cin_p - c1 < J.ck) ? (Cin_p - c1) : J.ck;
-                    stage_any<16, 64 * LW>(J.pro, S, smem + ((ic + 1) & 1) * tile_bytes, RS, c1, ck1, m0 - J.pad, rows, tid - 256);
-                }
-            }
-            else if (n_ok && !(J.dbg & 2))
-            {
-                const char *ab = abase + (ic & 1) * tile_bytes;
-                const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
-                const size_t wseg = (size_t)K * nicb * 64;
-                if (ck == 256 && J.ck == 256)
-                    mfma_taps<256, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
-                else if (ck == 128 && J.ck == 128)
-                    mfma_taps<128, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
-                else if (ck == 64 && J.ck == 64)
-                    mfma_taps<64, MT, NT, false>(acc, ab, dil * RS, wp, wseg, K);
-                else
-                    mfma_chunk<MT, NT>(acc, ab, RS, dil, wp, wseg, K, ck >> 4);
-            }
-            // the next chunk's tile is complete and this chunk's tile is free again
-            if (ic + 1 < nchunk) __syncthreads();
-        }
-        if (is_loader) return;
-    }
-    else
     for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
         if (c0) __syncthreads();
-        if (!(J.dbg & 1))
+        if (!(ZV_DBGBITS(J.dbg) & 1))
         {
             // an f16 operand tensor (the decoder's pre-pass output) in 16-byte pieces, a 64-row x 256-channel tile in ONE round
             // trip (9 pieces per thread in flight); the 8-byte pieces of stage_tile took four (phase stamps: 5.5-6.2 us per chunk)
@@ -788,7 +730,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
 #ifdef ZV_STAMPS
         if (stamp_k < 10) { ZV_STAMP(stamp_k) stamp_k++; }
 #endif
-        if (n_ok && !(J.dbg & 2))
+        if (n_ok && !(ZV_DBGBITS(J.dbg) & 2))
         {
             const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
             const size_t wseg = (size_t)K * nicb * 64;             // half8 units between consecutive output tiles
@@ -825,7 +767,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
     }
 
     // ---------------- epilogue ----------------
-    if (!n_ok || (J.dbg & 4)) return;
+    if (!n_ok || (ZV_DBGBITS(J.dbg) & 4)) return;
     const float escale = J.escale;
     const int tbase = m0 + wm * 32 * MT + 4 * (lane >> 5);
     const bool has_res = J.res != nullptr;
@@ -890,7 +832,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (LW > 0 || (NT == 2 && ZV_NT2_OCC ==
 #endif
 }
 
-template <int MT, int WN, int NT, bool SINGLE = false, int LW = 0>
+template <int MT, int WN, int NT, bool SINGLE = false>
 static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax, int Cout_p, int halo, int ck, int dmax_)
 {
     constexpr int WM = 4 / WN;
@@ -902,16 +844,16 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     jobs.stamp = knob(ZV_STAMP_CONV) && knob(ZV_STAMP_CONV) == (int)grid.y && njobs == 1 &&
                  (knob(ZV_STAMP_CIN) ? jobs.j[0].Cin_p == knob(ZV_STAMP_CIN) : jobs.j[0].Cin_p >= 1024);
 #endif
-    // + dil rows: mfma_taps prefetches one tap past the end; LW: two tile buffers
-    const size_t lds = (size_t)round_up((BM + halo + dmax_) * (ck * 2 + 16), 16) * (LW > 0 ? 2 : 1);
+    // + dil rows: mfma_taps prefetches one tap past the end
+    const size_t lds = (size_t)round_up((BM + halo + dmax_) * (ck * 2 + 16), 16);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE, LW>;
+    auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE>;
     if (lds > 64 * 1024)
     {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * LW), lds, s, jobs);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, jobs);
     return hipGetLastError();
 }
 
@@ -1052,7 +994,7 @@ static hipError_t launch_conv_stream(hipStream_t s, const ConvJob &job, int n_cu
 {
     ConvJobs js;
     js.j[0] = job;
-    js.j[0].dbg = knob(ZV_DBG);
+    js.j[0].dbg = diag_bits();
     for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     js.segs = segs;
     js.rate = rate;
@@ -1113,7 +1055,7 @@ hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, 
 
 static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, int nt_begin)
 {
-    const int dbg = knob(ZV_DBG);
+    const int dbg = diag_bits();
     ConvJobs js;
     js.segs = segs;
     js.rate = rate;
@@ -1179,21 +1121,6 @@ static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs
         {
             if (WN == 4) return launch_cfg<1, 4, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
             if (WN == 2) return launch_cfg<1, 2, 1, true>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
-        }
-    }
-    {
-        // batches, convs of several input-channel chunks (the wide decoder / encoder convs): loader waves + two tile buffers
-        // (ZV_CONV_LW = 0 never, 2 whenever the shape allows)
-        const int lw_env = knob(ZV_CONV_LW);
-        bool multi = true;
-        for (int i = 0; i < njobs; i++) multi = multi && jobs[i].Cin_p > jobs[i].ck;
-        const size_t tile2 = 2 * (size_t)round_up((32 * (MT >= 2 ? 2 : 1) * (4 / WN) + halo + dmax) * (ck * 2 + 16), 16);
-        if (lw_env && multi && WN == 4 && tile2 <= 80 * 1024 && (lw_env == 2 || wgs(MT, NT) >= 4L * n_cu))
-        {
-            // 64 x 32 per compute wave (147 registers: three waves per SIMD = two 6-wave workgroups per CU; the 64 x 64 and
-            // 128 x 32 wave tiles need 200+ registers and would leave the CU to one workgroup)
-            if (MT >= 2) return launch_cfg<2, 4, 1, false, 2>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
-            return launch_cfg<1, 4, 1, false, 2>(s, js, njobs, Lmax, Cout_p, halo, ck, dmax);
         }
     }
 #define ZV_CASE(mt, wn, nt) \
@@ -1348,12 +1275,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     constexpr int WN = CP / 32 / NT, WM = 4 / WN;
     constexpr int BM = 32 * MT * WM;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    // `interleave` jobs share their input (a block's first dilation pair): the branches of one stretch of the sequence run next
-    // to each other on the same XCD (blockIdx.x & 7 picks the XCD) on one common tiling, so only the first fetches it from HBM
-    const int il = MERGE ? 1 : jobs.interleave;
-    const int jz = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
-    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const int TM = BM - ((MERGE || il > 1) ? jobs.kmax - 1 : jobs.j[jz].K - 1);
+    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
     // workgroup -> (segment, time tile): every segment gets the tile count of the longest one, tiles past a segment's
     // end exit; the XCD map runs over the whole (segment, tile) range, so an XCD works on neighbouring tiles of
     // neighbouring utterances
@@ -1366,7 +1289,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     const int t0 = (vt - useg * tps) * TM;
     if (t0 >= L) return;
 #ifdef ZV_STAMPS
-    const int stamp_wg = il > 1 ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    const int stamp_wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
     if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
     {
         zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
@@ -1406,14 +1329,14 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     constexpr bool EARLY_B = CP <= 64 && !MERGE;
     half8 bw[4][NT];
     if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
-    if (!(P.dbg & 1)) stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+    if (!(ZV_DBGBITS(P.dbg) & 1)) stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
     ZV_STAMP(1)
     __syncthreads();
     ZV_STAMP(2)
 
     const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
     floatx16 acc[MT][NT];
-    if (P.dbg & 2)          // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
+    if (ZV_DBGBITS(P.dbg) & 2)          // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -1423,7 +1346,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
     if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw, (P.dbg & 32) ? 0 : 8 * 64);
+    if (!(ZV_DBGBITS(P.dbg) & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw, (ZV_DBGBITS(P.dbg) & 32) ? 0 : 8 * 64);
     if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
     ZV_STAMP(3)
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
@@ -1472,13 +1395,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
     if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);
-    if (!(P.dbg & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw, (P.dbg & 32) ? 0 : 8 * 64);
+    if (!(ZV_DBGBITS(P.dbg) & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw, (ZV_DBGBITS(P.dbg) & 32) ? 0 : 8 * 64);
 
     // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
     // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
     // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
     ZV_STAMP(6)
-    if (P.dbg & 4) return;
+    if (ZV_DBGBITS(P.dbg) & 4) return;
     const int nrows = (L - t0 < TM) ? (L - t0) : TM;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
     float *const outp = (!MERGE && P.sum_out) ? P.sum_out + (size_t)sg.row0 * jobs.rate * CP : out_seg;
@@ -1497,8 +1420,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
             float resv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                resv[r] = (P.dbg & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
-            if (P.dbg & 16) continue;
+                resv[r] = (ZV_DBGBITS(P.dbg) & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+            if (ZV_DBGBITS(P.dbg) & 16) continue;
             if constexpr (MERGE)
             {
 #pragma unroll
@@ -1590,12 +1513,8 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 {
     constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
     constexpr int CHUNK = 8 * 1024;                  // one tap: 4 channel steps x 2 output tiles
-    // `interleave` jobs share their input (a block's first dilation pair): the branches of one stretch of the sequence run next
-    // to each other on the same XCD (blockIdx.x & 7 picks the XCD) on one common tiling, so only the first fetches it from HBM
-    const int il = MERGE ? 1 : jobs.interleave;
-    const int jz = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
-    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const int TM = BM - ((MERGE || il > 1) ? jobs.kmax - 1 : jobs.j[jz].K - 1);
+    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
     const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
     if (vt >= tps * jobs.segs.nseg) return;
@@ -1606,7 +1525,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     if (t0 >= L) return;
 
 #ifdef ZV_STAMPS
-    const int stamp_wg = il > 1 ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    const int stamp_wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
     if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
     {
         zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
@@ -1652,7 +1571,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
         // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
         // (two workgroups per CU whatever the register count — LDS decides — so every staging load of the tile is in flight at once)
-        if (!(P.dbg & 1)) stage_act_buf<20, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+        if (!(ZV_DBGBITS(P.dbg) & 1)) stage_act_buf<20, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
         // the residual operand (the tile's centre rows again, in the accumulator layout) is requested right behind the
         // staging loads, while their lines are still in L2, and waits in registers until the epilogue
         const int nrows = (L - t0 < TM) ? (L - t0) : TM;
@@ -1666,7 +1585,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        resv[mt][nt][r] = (P.dbg & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff0 + nt * 128, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
+                        resv[mt][nt][r] = (ZV_DBGBITS(P.dbg) & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff0 + nt * 128, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
         };
         if constexpr (!MERGE) load_res();      // (the merged form holds the branches' running sum: it loads in the epilogue)
         ZV_STAMP(1)
@@ -1692,10 +1611,10 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
         const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
         ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
         ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
-        if (!(P.dbg & 64)) {                                                                              \
+        if (!(ZV_DBGBITS(P.dbg) & 64)) {                                                                              \
         if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                           \
-        if (!(P.dbg & 128)) __builtin_amdgcn_s_barrier();                                                 \
+        if (!(ZV_DBGBITS(P.dbg) & 128)) __builtin_amdgcn_s_barrier();                                                 \
         if (g + 3 < nchunk) issue(g + 3);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         ap += (tapstride);                                                                                \
@@ -1705,7 +1624,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
         g++;                                                                                              \
     }
         // ---- conv1 (dilated), transposed product
-        if (P.dbg & 2)
+        if (ZV_DBGBITS(P.dbg) & 2)
         {
 #pragma unroll
             for (int i = 0; i < MT; i++)
@@ -1778,7 +1697,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 
         ZV_STAMP(5)
         // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-        if (P.dbg & 2)
+        if (ZV_DBGBITS(P.dbg) & 2)
         {
             for (int tap = 0; tap < K; tap++)
             {
@@ -1806,7 +1725,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 
         // ---- epilogue: out = y + (conv2 + b2); descriptors over exactly this tile's valid rows (see resblock_pair_kernel)
         ZV_STAMP(6)
-        if (P.dbg & 4) return;
+        if (ZV_DBGBITS(P.dbg) & 4) return;
         if constexpr (MERGE) load_res();
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
 #pragma unroll
@@ -1818,7 +1737,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
             {
-                if (P.dbg & 16) continue;
+                if (ZV_DBGBITS(P.dbg) & 16) continue;
                 if constexpr (MERGE)
                 {
 #pragma unroll
@@ -1826,18 +1745,6 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
                     {
                         const float v = (acc[mt][nt][r] + bias) + resv[mt][nt][r];
                         msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
-                    }
-                    if (jb == 0 && jobs.merge_init)
-                    {
-                        // the sum's first term comes from memory (a branch that ran as a whole block): (init + out_0) + out_1
-                        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-                            (void *)(jobs.merge_init + (size_t)sg.row0 * jobs.rate * CP + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-                        float iv[16];
-#pragma unroll
-                        for (int r = 0; r < 16; r++)
-                            iv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
-#pragma unroll
-                        for (int r = 0; r < 16; r++) msum[mt][nt][r] = iv[r] + msum[mt][nt][r];
                     }
                     if (jb == jobs.njobs - 1)
 #pragma unroll
@@ -1867,7 +1774,6 @@ static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int
     constexpr int BM = 256;
     const int TMmin = BM - (Kmax - 1);
     dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);
-    if (!MERGE && js.interleave > 1) grid = dim3(grid.x * njobs, 1, 1);
     // operand rows: BM + (K - 1) * dil, + dil: the last tap's prefetch reads one tap past the end
     js.ring_off = round_up((BM + Kmax * dmax) * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
@@ -2128,9 +2034,6 @@ hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const
     js.rate = rate;
     js.interleave = 1;
     js.db_mask = 0;
-    js.sum_out = nullptr;
-    js.njobs = njobs;
-    js.hmax = 0;
     const int Lmax = segs.max_rows * rate;
     int gx = 1, rows_max = 0;
     for (int i = 0; i < njobs; i++)
@@ -2172,14 +2075,15 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     if (TMmin < 32) return hipErrorInvalidValue;
     // jobs differ in K: grid.x is sized for the smallest TM, workgroups beyond a job's extent exit at once
     dim3 grid(round_up(((Lmax + TMmin - 1) / TMmin) * js.segs.nseg, 8), 1, MERGE ? 1 : njobs);      // multiple of 8: zv_xcd_tile
-    if (!MERGE && js.interleave > 1) grid = dim3(grid.x * njobs, 1, 1);
     // rows touched: BM + taps (K rounded up to the loop's granularity, + 1 for the last prefetch) * dil.  The loop walks
     // whole taps once a tap is at least a body (CP >= 128): K + 1 taps (51 KB for the 128-channel stage: room for three
     // workgroups per CU instead of two — measured worth 0.6 %)
     // (CP = 256: exactly K taps — the prefetch one tap past the end reads rows that exist but are never used — so that the
     // 96-row tile of MT = 3 stays under 80 KB: two workgroups per CU)
-    // (ZV_LDS_PAD: diagnostic — extra bytes of LDS per workgroup, to measure a kernel at a lower occupancy)
-    const size_t lds = (size_t)(BM + (Kmax + (CP == 256 ? 0 : (CP >= 128 ? 1 : 4))) * dmax) * (CP * 2 + 16) + (size_t)knob(ZV_LDS_PAD);
+    size_t lds = (size_t)(BM + (Kmax + (CP == 256 ? 0 : (CP >= 128 ? 1 : 4))) * dmax) * (CP * 2 + 16);
+#ifdef ZV_DIAG
+    lds += (size_t)knob(ZV_LDS_PAD);       // diagnostic build: extra bytes of LDS per workgroup = a lower occupancy on purpose
+#endif
     auto kern = resblock_pair_kernel<CP, MT, MERGE>;
     if (lds > 64 * 1024)
     {
@@ -2190,36 +2094,34 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
     return hipGetLastError();
 }
 
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out, const float *merge_init)
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
-    const int dbg = knob(ZV_DBG), mt_env = knob(ZV_PAIR_MT);
+    const int dbg = diag_bits(), mt_env = knob(ZV_PAIR_MT);
     PairJobs js;
     js.segs = segs;
     js.rate = rate;
     js.njobs = njobs;
     js.merge_out = merge_out;
-    js.merge_init = merge_init;
-    if (merge_init && !merge_out) return hipErrorInvalidValue;
 #ifdef ZV_STAMPS
     js.stamp = knob(ZV_STAMP_CP) && knob(ZV_STAMP_CP) == jobs[0].Cp && !merge_out;
 #endif
     const int Lmax = segs.max_rows * rate;
     int Kmax = 0, dmax = 0;
-    bool same_in = njobs > 1 && !merge_out;
     for (int i = 0; i < njobs; i++)
     {
         js.j[i] = jobs[i];
         js.j[i].dbg = dbg;
-        same_in = same_in && jobs[i].y == jobs[0].y;
         if (jobs[i].Cp != jobs[0].Cp) return hipErrorInvalidValue;
         Kmax = jobs[i].K > Kmax ? jobs[i].K : Kmax;
         dmax = jobs[i].dil > dmax ? jobs[i].dil : dmax;
     }
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
-    // batches whose jobs read the same tensor: branches interleaved per XCD (ZV_PAIR_INTERLEAVE = 0 never, 2 at any length)
-    const int il_env = knob(ZV_PAIR_INTERLEAVE);
-    js.interleave = (same_in && il_env && (il_env == 2 || (long)Lmax * segs.nseg >= 2048L * n_cu)) ? njobs : 1;
+    // the running MRF sum (PairJob::sum_in / sum_out) exists only in resblock_pair_kernel<CP, MT, false>: not together with the
+    // merged form, and not on the 64-channel ring kernel (which would silently write P.out instead)
+    bool any_sum = false;
+    for (int i = 0; i < njobs; i++) any_sum = any_sum || jobs[i].sum_out || jobs[i].sum_in;
+    if (any_sum && merge_out) return hipErrorInvalidValue;
     const int Cp = jobs[0].Cp;
     const int WN = Cp == 256 ? 4 : Cp / 32;
     auto wgs = [&](int MT) {
@@ -2237,7 +2139,7 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
     // 64 channels, batches: the form with the weights through an LDS ring (ZV_PAIR64_RING = 0 never, 2 whenever it fits)
     {
         const int ring_env = knob(ZV_PAIR64_RING);
-        bool ok = Cp == 64 && ring_env != 0 && Kmax >= 3 && (256 + Kmax * dmax) * 144 + 4 * 8192 + 1024 <= 80 * 1024;
+        bool ok = Cp == 64 && !any_sum && ring_env != 0 && Kmax >= 3 && (256 + Kmax * dmax) * 144 + 4 * 8192 + 1024 <= 80 * 1024;
         for (int i = 0; i < njobs && ok; i++) ok = jobs[i].w1r && jobs[i].w2r;
         const long rwgs = (long)((Lmax + 256 - Kmax) / (257 - Kmax)) * segs.nseg * njobs;
         if (ok && (ring_env == 2 || rwgs >= 6L * n_cu))
@@ -2246,7 +2148,6 @@ hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, 
             return merge_out ? launch_pair64_ring<true>(s, js, njobs, Lmax, Kmax, dmax) : launch_pair64_ring<false>(s, js, njobs, Lmax, Kmax, dmax);
         }
     }
-    if (merge_init) return hipErrorInvalidValue;          // (only the 64-channel ring kernel's merged form takes a first term from memory)
     int MT = (Cp == 128 && wgs(4) >= 8L * n_cu) ? 4 : 2;
     // 256 channels, batches: 96-row tiles (two thirds of the weight-fragment traffic per row, 10 instead of 16 % of conv2 spent
     // on halo rows at 11 taps; 80 KB of LDS and 234 registers still give two workgroups per CU): 1 010 -> 897 us per launch.
@@ -2353,12 +2254,12 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
 
         // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
         floatx16 acc[MT][1];
-        if (P.dbg & 2)      // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
+        if (ZV_DBGBITS(P.dbg) & 2)      // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
-        if (!(P.dbg & 2))
+        if (!(ZV_DBGBITS(P.dbg) & 2))
             mfma_taps_deep<CP, MT, 1, true>(acc, abase + (XM - h1) * RS, dil * RS, (const half8 *)P.w1[d] + lane, wseg, K, bw);
         deep_preload_b<1>(bw, (const half8 *)P.w2[d] + lane, wseg);                 // under the xt pack
         __syncthreads();                       // every wave is done reading X: the region becomes XT
@@ -2394,7 +2295,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
         __syncthreads();
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        if (!(P.dbg & 2))
+        if (!(ZV_DBGBITS(P.dbg) & 2))
             mfma_taps_deep<CP, MT, 1, false>(acc, abase + (XM - h2) * RS, RS, (const half8 *)P.w2[d] + lane, wseg, K, bw);
         if (d + 1 < nd) deep_preload_b<1>(bw, (const half8 *)P.w1[d + 1] + lane, wseg);      // under the epilogue and the next X write
         {
@@ -2422,7 +2323,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT)) void resblock_triple_kernel(con
     }
 
     // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
-    if (P.dbg & 4) return;
+    if (ZV_DBGBITS(P.dbg) & 4) return;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -2525,28 +2426,22 @@ __device__ __forceinline__ void pack_all(unsigned pa, const uint2 (&pk)[MT_][4])
     if constexpr (I + 1 < MT_ * 4) pack_all<MT_, I + 1>(pa, pk);
 }
 
-template <int MT, int R, bool SUM>
+template <int MT, int R>
 __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32_kernel(const TripleJobs jobs)
 {
     constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
     // workgroup -> (job, tile): with `il` jobs interleaved the MRF branches of one stretch of the sequence run next to each
     // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM.
-    // jobs.sum_out: ONE workgroup runs every job of its tile, one after the other on one common tiling, and only the running
-    // sum (out_0 + out_1) + out_2 exists in memory: job j > 0 reads the sum back (from L2: this workgroup stored it a block
-    // earlier), adds its own output and stores it again — the output conv then reads one tensor instead of three.
-    constexpr bool sum_mode = SUM;
-    const int il = sum_mode ? 1 : jobs.interleave;
+    const int il = jobs.interleave;
     const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const int j_first = sum_mode ? 0 : (il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z);
-    const int j_end = sum_mode ? jobs.njobs : j_first + 1;
-    // the tiling: the job's own halo, or in sum mode the widest halo of the jobs (jobs.hmax) for all of them
+    const int jb = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
+    const TripleJob &P = jobs.j[jb];
     int H;
     {
-        const TripleJob &P0 = jobs.j[j_first];
         int sumd0 = 0;
-        for (int d = 0; d < P0.n_dil; d++) sumd0 += P0.dil[d];
-        H = sum_mode ? jobs.hmax : ((P0.K - 1) / 2) * (sumd0 + P0.n_dil);
+        for (int d = 0; d < P.n_dil; d++) sumd0 += P.dil[d];
+        H = ((P.K - 1) / 2) * (sumd0 + P.n_dil);
     }
     const int TM = R - 2 * H;
     const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
@@ -2570,9 +2465,6 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #endif
     ZV_STAMP(0)
 
-    for (int jb = j_first; jb < j_end; jb++)
-    {
-    const TripleJob &P = jobs.j[jb];
     const int K = P.K, nd = P.n_dil;
     const int h2 = (K - 1) / 2;
     int dmax = 1;
@@ -2593,12 +2485,6 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
     char *wlds = smem + round_up(xrows * RS, 1024);
     char *wlds2 = db ? wlds + nblk * 1024 : wlds;                  // conv2's weights
     float *blds = (float *)(wlds + (db ? 2 : 1) * nblk * 1024 + 2048);      // behind the last-prefetch slack: [d][conv][32]
-    if (jb > j_first)
-    {
-        // the previous job's last conv2 is done reading the operand region and its weights
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
     dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
     if (tid < 64 * nd)
     {
@@ -2650,12 +2536,12 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 
         // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
         floatx16 acc[MT][1];
-        if (P.dbg & 2)
+        if (ZV_DBGBITS(P.dbg) & 2)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
-        if (!(P.dbg & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, K);
+        if (!(ZV_DBGBITS(P.dbg) & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, K);
 #ifdef ZV_STAMPS
         if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
 #endif
@@ -2709,7 +2595,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #endif
 
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        if (!(P.dbg & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
+        if (!(ZV_DBGBITS(P.dbg) & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
         {
             const float bias = bias2;
             if (edge)
@@ -2735,49 +2621,19 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
     }
 
     // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
-    if (P.dbg & 4) return;
-    float *const out_seg = (sum_mode ? jobs.sum_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
+    if (ZV_DBGBITS(P.dbg) & 4) return;
+    float *const out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
-    // (the 32 store offsets do not depend on the job: hipcc would compute them once, ahead of the job loop, and spill them)
-    int irow_e = irow0;
-    if constexpr (sum_mode) asm volatile("" : "+v"(irow_e));
-    if (sum_mode && jb > j_first)
-    {
-        // the running sum of the jobs before this one: stored by these very lanes, long ago — the wait costs nothing — and read
-        // back past the CU's vector cache (sc0 sc1), which may still hold the line as the job before last left it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-        {
-            float sv[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int i = irow_e + mt * 32 + (r & 3) + 8 * (r >> 2);
-                const int t = t0 - H + i;
-                const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
-                sv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, voff, 0, 17));
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) yreg[mt][r] = sv[r] + yreg[mt][r];
-        }
-    }
-    const bool last_job = jb + 1 == j_end;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
         {
-            const int i = irow_e + mt * 32 + (r & 3) + 8 * (r >> 2);
+            const int i = irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
             const int t = t0 - H + i;
             const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
-            // (a running sum that this workgroup reads again stays in L2; everything else leaves for the next launch)
-            if (last_job)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, ZV_ST_AUX);
-            else
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, ZV_ST_AUX);
         }
-    }
 #ifdef ZV_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ZV_STAMP(11)
@@ -2797,55 +2653,19 @@ bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 static void triple_tile(int njobs, int n_cu, const Segs &segs, int rate, int &MT, int &R)
 {
     const int Lmax = segs.max_rows * rate;
-    const int cfg_env = knob(ZV_TRIPLE_CFG);          // A/B hook: MT*1000 + R
-    R = (long)Lmax * segs.nseg * njobs >= 7000L * n_cu ? 512 : 256;
+    R = ((long)Lmax * segs.nseg * njobs >= 7000L * n_cu || knob(ZV_TRIPLE_V2) == 3) ? 512 : 256;      // (ZV_TRIPLE_V2 = 3: tests force the batches' tile)
     MT = 2;
-    if (cfg_env) { MT = cfg_env / 1000; R = cfg_env % 1000; }
 }
 
-static int triple_halo(const TripleJob &P)
-{
-    int sumd = 0;
-    for (int d = 0; d < P.n_dil; d++) sumd += P.dil[d];
-    return ((P.K - 1) / 2) * (sumd + P.n_dil);
-}
-
-// true when launch_triple(..., sum_out) can run every job of a tile in one workgroup and store only their sum: the form with
-// the weights in LDS on 512-row tiles, and about four rounds of such (three times as long) workgroups — ZV_BLOCK_SUM = 0
-// never, 2 whenever the kernel form allows
-bool triple_can_sum(const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
-{
-    const int env = knob(ZV_BLOCK_SUM), v2_env = knob(ZV_TRIPLE_V2);
-    if (!env || njobs < 2 || njobs > PAIR_MAX_JOBS || !v2_env) return false;
-    int MT, R;
-    triple_tile(njobs, n_cu, segs, rate, MT, R);
-    if (MT != 2 || (R != 512 && !(R == 256 && v2_env == 2))) return false;
-    int hmax = 0;
-    for (int i = 0; i < njobs; i++)
-    {
-        if (jobs[i].y != jobs[0].y || !triple_supported(jobs[i].Cp, jobs[i].K, jobs[i].dil, jobs[i].n_dil)) return false;
-        hmax = std::max(hmax, triple_halo(jobs[i]));
-    }
-    const int TM = R - 2 * hmax;
-    if (TM < R / 4) return false;
-    const long wgs = (long)((segs.max_rows * rate + TM - 1) / TM) * segs.nseg;
-    return env == 2 || wgs >= 8L * n_cu;
-}
-
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *sum_out)
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate)
 {
     if (njobs < 1 || njobs > PAIR_MAX_JOBS || segs.nseg < 1 || segs.max_rows < 1) return hipErrorInvalidValue;
-    if (sum_out && !triple_can_sum(jobs, njobs, n_cu, segs, rate)) return hipErrorInvalidValue;
-    const int dbg = knob(ZV_DBG);
+    const int dbg = diag_bits();
     TripleJobs js;
     js.segs = segs;
     js.rate = rate;
     js.interleave = 1;
     js.db_mask = 0;
-    js.sum_out = sum_out;
-    js.njobs = njobs;
-    js.hmax = 0;
-    for (int i = 0; i < njobs; i++) js.hmax = std::max(js.hmax, triple_halo(jobs[i]));
 #ifdef ZV_STAMPS
     js.stamp = knob(ZV_STAMP_CP) == 32;
 #endif
@@ -2862,7 +2682,7 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         if (P.Cp != jobs[0].Cp || !triple_supported(P.Cp, P.K, P.dil, P.n_dil)) return hipErrorInvalidValue;
         int sumd = 0, dmax = 1;
         for (int d = 0; d < P.n_dil; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
-        const int h2 = (P.K - 1) / 2, TM = R - 2 * (sum_out ? js.hmax : h2 * (sumd + P.n_dil));
+        const int h2 = (P.K - 1) / 2, TM = R - 2 * h2 * (sumd + P.n_dil);
         gx = std::max(gx, ((Lmax + TM - 1) / TM) * segs.nseg);
         const size_t rows = R + 2 * h2 * dmax + 5 * dmax;
         lds = std::max(lds, rows * (P.Cp * 2 + 16));
@@ -2870,9 +2690,9 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
     for (int i = njobs; i < PAIR_MAX_JOBS; i++) js.j[i] = js.j[0];
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(round_up(gx, 8), 1, njobs);      // multiple of 8: zv_xcd_tile
-    // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always (A/B, tests)
+    // batches: the form with the weights in LDS (two workgroups per CU); ZV_TRIPLE_V2 = 0 never, 2 always, 3 always and on 512-row tiles (A/B, tests)
     const int v2_env = knob(ZV_TRIPLE_V2);
-    if ((MT == 2 || (MT == 4 && R == 512)) && (R == 512 || R == 256) && v2_env && (R == 512 || v2_env == 2))
+    if (v2_env && (R == 512 || v2_env >= 2))
     {
         size_t lds2 = 0;
         js.db_mask = 0;
@@ -2891,23 +2711,20 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
         }
         if (lds2 <= 80 * 1024)
         {
-            js.interleave = (knob(ZV_TRIPLE_INTERLEAVE) != 0 && !sum_out) ? njobs : 1;
-            const dim3 grid2 = sum_out ? dim3(round_up(gx, 8), 1, 1) : (js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid);
+            js.interleave = knob(ZV_TRIPLE_INTERLEAVE) != 0 ? njobs : 1;
+            const dim3 grid2 = js.interleave > 1 ? dim3(round_up(gx, 8) * njobs, 1, 1) : grid;
             auto launch = [&](auto kern, int nth) {
                 hipError_t e = lds2 > 64 * 1024 ? hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) : hipSuccess;
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
-            if (sum_out) return R == 512 ? launch(resblock_block32_kernel<2, 512, true>, 512) : launch(resblock_block32_kernel<2, 256, true>, 256);
-            if (MT == 4) return launch(resblock_block32_kernel<4, 512, false>, 256);
-            return R == 512 ? launch(resblock_block32_kernel<2, 512, false>, 512) : launch(resblock_block32_kernel<2, 256, false>, 256);
+            return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
         }
     }
-    if (sum_out) return hipErrorInvalidValue;          // (triple_can_sum said the form above fits)
 #define ZV_TCASE(mt, r) \
     if (MT == mt && R == r) { hipLaunchKernelGGL((resblock_triple_kernel<32, mt, r>), grid, dim3(64 * (r / 32 / mt)), lds, s, js); return hipGetLastError(); }
-    ZV_TCASE(2, 256) ZV_TCASE(2, 512) ZV_TCASE(1, 256) ZV_TCASE(4, 512)
+    ZV_TCASE(2, 256) ZV_TCASE(2, 512)
 #undef ZV_TCASE
     return hipErrorInvalidValue;
 }
@@ -3047,10 +2864,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
 
     // descriptors: the utterance's rows of the operand tensor (anything outside reads as zero = the conv's zero padding) and
     // this group's weight stream (groups before the last one have 8 tiles)
-    // (J.dbg, timing ablations only: bit 1 / bit 2 = the operand / weight descriptor covers nothing, every piece arrives as zeros
+    // (ZV_DBGBITS(J.dbg), timing ablations only: bit 1 / bit 2 = the operand / weight descriptor covers nothing, every piece arrives as zeros
     // without touching memory)
-    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (J.dbg & 1) ? 0u : (unsigned)((size_t)L * ldx * 2));
-    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (J.dbg & 2) ? 0u : (unsigned)((size_t)nunits * bunit));
+    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (ZV_DBGBITS(J.dbg) & 1) ? 0u : (unsigned)((size_t)L * ldx * 2));
+    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (ZV_DBGBITS(J.dbg) & 2) ? 0u : (unsigned)((size_t)nunits * bunit));
 
     // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
     // slot); the slot holds the 16-byte piece (slot ^ ((row >> 2) & 3)) of the row's 64 bytes
@@ -3088,7 +2905,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
     };
     // per half and wave: two operand pieces, two weight fragments (+ one more for waves 0 and 1 where a ninth tile rides along:
     // 18 fragments); the same count in every half, so the counted waits below hold
-    const bool no_dma = (J.dbg & 4) != 0;          // timing ablation: no piece is requested at all (the loop runs on stale LDS)
+    const bool no_dma = (ZV_DBGBITS(J.dbg) & 4) != 0;          // timing ablation: no piece is requested at all (the loop runs on stale LDS)
     auto issue_pa = [&](int i) {
         if (!no_dma) dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff));
     };
@@ -3342,7 +3159,7 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
 {
     ConvJobs js;
     js.j[0] = job;
-    js.j[0].dbg = knob(ZV_DBG);
+    js.j[0].dbg = diag_bits();
     for (int i = 1; i < CONV_MAX_JOBS; i++) js.j[i] = js.j[0];
     js.segs = segs;
     js.rate = rate;
@@ -3355,13 +3172,9 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
     // (grid.x covers (row tile, group) in the kernel's XCD-aware order: 8 / ng XCDs per group)
     const dim3 grid((js.order == 1 && (ng == 1 || ng == 2 || ng == 4)) ? round_up(rts, 8 / ng) * ng : rts * ng, 1, 1);
     const int lds = 4 * (16384 + 18432);
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        hipError_t e = hipFuncSetAttribute((const void *)conv_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // (per launch, like every other launcher here: the attribute is stored per device)
+    hipError_t e = hipFuncSetAttribute((const void *)conv_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(512), lds, s, js);
     return hipGetLastError();
 }

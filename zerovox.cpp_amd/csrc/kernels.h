@@ -10,6 +10,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-only ablation bits (`dbg` fields of the job structs: skip staging / MFMA loops / stores ... — WRONG results) exist only
+// in diagnostic builds (-DZV_DIAG, see knobs.h).  In the shipped library every read of them is the constant 0 and the code
+// they select is compiled out.
+#ifdef ZV_DIAG
+#define ZV_DBGBITS(x) (x)
+#else
+#define ZV_DBGBITS(x) 0
+#endif
+
 namespace zv
 {
 
@@ -170,12 +179,10 @@ struct PairJobs
     Segs    segs;
     int     rate;
     int     njobs, kmax;
-    int     interleave;          // > 1: that many jobs read the same input and run interleaved per XCD on one common tiling (grid.z = 1)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
     float  *merge_out;           // non-null: store (out_0 + out_1) + out_2 here instead of the jobs' own outputs
-    const float *merge_init;     // resblock_pair64_kernel<true>: the sum's first term comes from memory: (init + out_0) + out_1
     int     ring_off;            // resblock_pair64_kernel: byte offset of the weight ring in LDS (set by the launcher)
 };
 // true when a ResBlock conv pair with Cp (padded) channels and K taps can run on the fused kernel
@@ -188,8 +195,7 @@ size_t     pair_ring_weight_halfs(int Cp, int K);
 void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
 // merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
 // stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
-hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr,
-                       const float *merge_init = nullptr);
+hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);
 
 // ---- a whole HiFi-GAN residual block (reference src/hifigan.cpp:74-185: the loop over all dilations) in ONE launch:
 // a workgroup keeps a 256-row f32 tile of y in LDS, runs the n_dil fused pairs on it and writes the centre rows once.
@@ -215,8 +221,6 @@ struct TripleJobs
     int       interleave;        // resblock_block32_kernel: > 1 = that many jobs share grid.x, interleaved per XCD
     int       db_mask;           // resblock_block32_kernel: bit j = job j keeps two weight buffers in LDS (set by the launcher)
     int       ring_off;          // resblock_block64_kernel: byte offset of the weight ring in LDS (set by the launcher)
-    float    *sum_out;           // resblock_block32_kernel: non-null = a workgroup runs all `njobs` jobs of its tile and stores only
-    int       njobs, hmax;       //   their sum (out_0 + out_1) + out_2 here, on the common tiling of the widest halo `hmax`
 #ifdef ZV_STAMPS
     int       stamp;
 #endif
@@ -226,9 +230,7 @@ bool       triple_supported(int Cp, int K, const int *dil, int n_dil);
 // several dilation pairs of a 64-channel block in one launch (resblock_block64_kernel): w1 / w2 in pack_pair_weight_ring layout
 bool       block64_supported(int Cp, int K, const int *dil, int n_dil);
 hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const Segs &segs, int rate);
-// sum_out (may be null; only when triple_can_sum): the jobs share their input and only (out_0 + out_1) + out_2 is stored, there
-bool       triple_can_sum(const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
-hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *sum_out = nullptr);
+hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
 // ---- vocoder tail: lrelu(0.01) -> conv k7 (C -> 1) + b -> tanh (src/hifigan.cpp:324-345) ----------
 struct OutConvArgs

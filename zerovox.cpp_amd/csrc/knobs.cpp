@@ -15,10 +15,12 @@ struct Entry
     int         value, dflt;
 };
 #define ZV_KNOB_ENTRY(n, d) {#n, d, d},
-Entry g_knobs[ZV_KNOB_COUNT] = {ZV_KNOB_LIST(ZV_KNOB_ENTRY)};
+Entry g_knobs[ZV_KNOB_COUNT] = {ZV_KNOB_LIST(ZV_KNOB_ENTRY) ZV_KNOB_LIST_DIAG(ZV_KNOB_ENTRY)};
+unsigned g_epoch = 0;
 #undef ZV_KNOB_ENTRY
 
-// the one place the environment is read: when the library is loaded
+#ifdef ZV_DIAG
+// diagnostic builds: the one place the environment is read, when the library is loaded
 struct Init
 {
     Init()
@@ -27,6 +29,7 @@ struct Init
             if (const char *v = getenv(e.name)) e.value = atoi(v);
     }
 } g_init;
+#endif
 }  // namespace
 
 int knob(Knob k) { return g_knobs[k].value; }
@@ -36,6 +39,20 @@ const char *knob_name(int k) { return k >= 0 && k < ZV_KNOB_COUNT ? g_knobs[k].n
 void knob_reset()
 {
     for (Entry &e : g_knobs) e.value = e.dflt;
+    g_epoch++;
+}
+
+unsigned knob_epoch() { return g_epoch; }
+
+bool knob_get(const char *name, int *value)
+{
+    for (Entry &e : g_knobs)
+        if (strcmp(e.name, name) == 0)
+        {
+            *value = e.value;
+            return true;
+        }
+    return false;
 }
 
 bool knob_set(const char *name, int value)
@@ -44,6 +61,7 @@ bool knob_set(const char *name, int value)
         if (strcmp(e.name, name) == 0)
         {
             e.value = value;
+            g_epoch++;
             return true;
         }
     return false;

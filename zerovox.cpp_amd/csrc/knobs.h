@@ -1,9 +1,9 @@
 // knobs.h — the library's test / measurement switches in ONE table.
 //
 // None is needed in production.  Tests force a kernel regime (the regimes give the same bits), measurements A/B a tile
-// shape.  The table is filled once, when the library is loaded, from environment variables of the same names (so a
-// shell script can still A/B a run), and changed afterwards only through the C-ABI test entry zv_debug_set(name, value):
-// no launch path reads the environment.
+// shape.  The table changes only through the C-ABI test entry zv_debug_set(name, value) — the shipped library never reads
+// the environment (the Python test / bench binding forwards ZV_* variables through that entry, so a shell script can still
+// A/B a run); a diagnostic build (-DZV_DIAG) also fills it from the environment when it is loaded.
 #pragma once
 
 namespace zv
@@ -18,12 +18,9 @@ namespace zv
     X(ZV_MERGE_ALWAYS, 0)      /* 1: the merged MRF sum at any length (default: only with rounds of workgroups to spare) */           \
     X(ZV_MERGE_SEQ, 1)         /* 0: the 256-channel stage's MRF sum by one three-branch workgroup per tile instead of three launches */ \
     X(ZV_MERGE_MAXC, 256)      /* widest stage whose last dilation pair stores the merged sum (batches) */                            \
-    X(ZV_VOC_GROUP, 0)         /* G > 0: the vocoder runs G utterances at a time (experiment) */                                      \
-    X(ZV_LANE_ORDER, 0)        /* batches in flight on different lanes: 0 share the GPU freely, 1 a batch's head waits for the previous batch's head, 2 for all of it */ \
     X(ZV_TAIL_GROUPS, 8)       /* utterance groups of a batch's last vocoder stage */                                                 \
     X(ZV_ARENA_FILL, 0)        /* byte a fresh activation arena is filled with (255: NaN patterns) */                                 \
     X(ZV_DEC_PREPASS, -1)      /* -1 auto, 0 decoder convs normalise on the fly, 1 f16 operand pass */                                \
-    X(ZV_DBG, 0)               /* timing-only ablation bits (wrong results) */                                                        \
     X(ZV_CONV_MT, 0)           /* minimum tile height of the generic conv kernel */                                                   \
     X(ZV_CONV_NT, 0)           /* 1 / 2: output tiles per wave of the generic conv kernel */                                          \
     X(ZV_CONV_SINGLE, 1)       /* 0: never the single-utterance MFMA loop, 2: also for one-chunk convs */                             \
@@ -31,28 +28,33 @@ namespace zv
     X(ZV_CONV_STREAM, 1)       /* 0 never, 1 batches, 2 always: memory-bound 3-tap convs (the last upsample convs) on conv_stream_kernel */ \
     X(ZV_UP_GEMM, 1)           /* 0 never, 1 batches, 2 always: the wide upsample convs behind an f16 operand pass on conv_gemm_kernel */ \
     X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 1 one group per XCD, 2 the 9-tile group first */ \
-    X(ZV_CONV_LW, 0)           /* 0 never, 1 batches, 2 always: loader waves + double-buffered tile for multi-chunk convs */          \
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
-    X(ZV_PAIR_INTERLEAVE, 0)   /* 0 never, 1 batches, 2 always: pair launches whose jobs share their input run the branches interleaved per XCD (measured: 0 … +3 %) */ \
     X(ZV_BLOCK64, 3)           /* 64-channel stage of a batch: branches with at most that many taps run their first two dilation pairs in one launch (resblock_block64_kernel); 0 never, negative: at any length */ \
-    X(ZV_BLOCK64_ALL, 0)       /* 1: resblock_block64_kernel runs the first branch's WHOLE block, its output the merged sum's first term (measured: the same time as two of its three pairs) */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
-    X(ZV_BLOCK_SUM, 0)         /* 0 never, 1 batches, 2 always: the whole-block kernel runs the three branches of a tile in one workgroup and stores their sum (measured: output conv -0.37 ms, blocks +0.66 ms per batch) */ \
-    X(ZV_TRIPLE_CFG, 0)        /* MT * 1000 + R of the whole-block kernel */                                                          \
-    X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always: whole-block kernel with its weights in LDS */                         \
+    X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always, 3 always on 512-row tiles: whole-block kernel with its weights in LDS */                      \
     X(ZV_TRIPLE_DB, 1)         /* 0: one weight buffer for every branch */                                                            \
     X(ZV_TRIPLE_INTERLEAVE, 1) /* 0: branches not interleaved per XCD */                                                              \
     X(ZV_ATT_SCALAR, 0)        /* 1: scalar attention kernel */                                                                       \
-    X(ZV_ATT_MFMA, 0)          /* 1: matrix-core attention kernel whatever the size */                                                \
+    X(ZV_ATT_MFMA, 0)          /* 1: matrix-core attention kernel whatever the size */
+
+// Diagnostic builds only (-DZV_DIAG: scripts/stamps*.py, ablation timings): switches that produce WRONG results or change
+// occupancy on purpose.  The shipped library does not contain them, nor the code they select (kernels.h: ZV_DBGBITS).
+#ifdef ZV_DIAG
+#define ZV_KNOB_LIST_DIAG(X)                                                                                                          \
+    X(ZV_DBG, 0)               /* timing-only ablation bits (wrong results) */                                                        \
     X(ZV_LDS_PAD, 0)           /* diagnostic: extra bytes of LDS per workgroup of the pair kernels (a lower occupancy on purpose) */ \
     X(ZV_STAMP_CP, 0)          /* diagnostic build: channel count of the pair launches that write phase stamps */                     \
     X(ZV_STAMP_CONV, 0)        /* diagnostic build: grid.y of the conv launches that write phase stamps */                            \
     X(ZV_STAMP_CIN, 0)         /* diagnostic build: their input channels */
+#else
+#define ZV_KNOB_LIST_DIAG(X)
+#endif
 
 enum Knob : int
 {
 #define ZV_KNOB_ENUM(n, d) n,
     ZV_KNOB_LIST(ZV_KNOB_ENUM)
+    ZV_KNOB_LIST_DIAG(ZV_KNOB_ENUM)
 #undef ZV_KNOB_ENUM
     ZV_KNOB_COUNT
 };
@@ -62,6 +64,16 @@ int         knob(Knob k);
 bool        knob_set(const char *name, int value);
 // every knob back to its built-in default
 void        knob_reset();
+// false when no knob has that name
+bool        knob_get(const char *name, int *value);
+// bumped by every knob_set / knob_reset: captured graphs are keyed on it (a graph replays the regime it was captured in)
+unsigned    knob_epoch();
 const char *knob_name(int k);
+// the timing-only ablation bits handed to the kernels: ZV_DBG in a diagnostic build, always 0 in the shipped library
+#ifdef ZV_DIAG
+inline int diag_bits() { return knob(ZV_DBG); }
+#else
+inline int diag_bits() { return 0; }
+#endif
 
 }  // namespace zv

@@ -614,8 +614,9 @@ constexpr int ATT_LDS_MAX = 160 * 1024 - 4096;
 
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                              const float *__restrict__ v, int ld, int dk, float inv_temp,
-                                                             float *__restrict__ o, int ldo, const Segs segs, int dbg)
+                                                             float *__restrict__ o, int ldo, const Segs segs, int dbg_arg)
 {
+    const int dbg = ZV_DBGBITS(dbg_arg);        // timing-only ablation bits: diagnostic builds only (kernels.h)
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
     __shared__ float redm[4][64];
     __shared__ double redd[4][64];
@@ -904,7 +905,7 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((n + 63) / 64, H, segs.nseg), dim3(256), lds_mfma, s, q, k, v, ld, dk, inv_temp, o, ldo, segs, knob(ZV_DBG) >> 8);
+        hipLaunchKernelGGL(kern, dim3((n + 63) / 64, H, segs.nseg), dim3(256), lds_mfma, s, q, k, v, ld, dk, inv_temp, o, ldo, segs, diag_bits() >> 8);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(dk + n) * sizeof(float);

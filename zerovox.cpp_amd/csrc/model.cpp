@@ -169,7 +169,6 @@ Model::Model(const std::string &path, int dev) : device(dev)
     no_triple_ = knob(ZV_NO_TRIPLE) != 0;
     force_fuse256_ = knob(ZV_FUSE256) != 0;
     no_merge_ = knob(ZV_NO_MERGE) != 0;
-    voc_group_ = knob(ZV_VOC_GROUP);
     tail_groups_ = knob(ZV_TAIL_GROUPS);
     ZV_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     lanes_.resize(1);
@@ -479,8 +478,12 @@ Model::~Model()
         for (hipEvent_t e : tail_events_) hipEventDestroy(e);
         if (copy_stream_) hipStreamDestroy(copy_stream_);
     }
-    for (hipEvent_t e : order_events_) hipEventDestroy(e);
-    order_events_.clear();
+    for (hipEvent_t &e : batch_events_)
+        if (e)
+        {
+            hipEventDestroy(e);
+            e = nullptr;
+        }
     for (Lane &l : lanes_)
     {
         if (l.copy_stream) hipStreamSynchronize(l.copy_stream);
@@ -501,16 +504,11 @@ hipStream_t Model::copy_stream()
     return copy_stream_;
 }
 
-hipEvent_t Model::order_event(int lane, int which)
+hipEvent_t Model::batch_event(uint64_t seq, int which)
 {
-    const int i = 2 * lane + which;
-    while ((int)order_events_.size() <= i)
-    {
-        hipEvent_t e;
-        ZV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        order_events_.push_back(e);
-    }
-    return order_events_[i];
+    hipEvent_t &e = batch_events_[2 * (seq % BATCH_RING) + which];
+    if (!e) ZV_HIP(hipEventCreate(&e));
+    return e;
 }
 
 hipEvent_t Model::tail_event(int i)
@@ -820,19 +818,6 @@ static double conv_flops(double L, int Cin, int Cout, int K) { return 2.0 * L * 
 void Model::vocode_dev(const Batch &bt, const float *d_mel, float *d_wav)
 {
     if (bt.t_rows == 0 || bt.t_max <= 0) fail(ZV_ERR_ARG, "T must be > 0");
-    // ZV_VOC_GROUP=G (experiment): the vocoder runs G utterances at a time, so that the tensors one launch hands to the
-    // next stay in the 256 MiB Infinity Cache instead of crossing HBM twice; same buffers, same row ranges, same bits
-    if (voc_group_ > 0 && bt.d_frm && bt.nseg > voc_group_ && dbg_layer.kind < 0)
-    {
-        for (int g0 = 0; g0 < bt.nseg; g0 += voc_group_)
-        {
-            Batch sub = bt;
-            sub.d_frm = bt.d_frm + g0;
-            sub.nseg = std::min(voc_group_, bt.nseg - g0);
-            vocode_group(sub, d_mel, d_wav);
-        }
-        return;
-    }
     vocode_group(bt, d_mel, d_wav);
 }
 
@@ -1024,20 +1009,14 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 }
                 ycur[jb] = y[jb];
             }
-            // batches: a workgroup runs the three branches of its tile and only their sum is stored (the next launch reads one
-            // tensor); a debug run of one block needs that block's own output
-            const bool sum3 = !no_merge_ && !dbg_here && triple_can_sum(tj, 3, n_cu, fr, rate);
-            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate, sum3 ? y[0] : nullptr));
-            if (sum3) merged_sum = y[0];
+            ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_triple(stream, tj, 3, n_cu, fr, rate));
         }
         // 64 channels, batches: the first two dilation pairs of the branches with few taps in ONE launch (resblock_block64_kernel:
         // the branch's tensor crosses HBM once instead of twice; ZV_BLOCK64 = most taps it takes, 0 = never; negative: at any length)
         bool b64[3] = {false, false, false};
-        bool b64_full0 = false;       // ... and the FIRST branch all three of them: its output is then the first term of the merged MRF sum
         {
             const int k64 = knob(ZV_BLOCK64);
             const int kmax64 = k64 < 0 ? -k64 : k64;
-            const bool merge_later = !no_merge_ && !dbg_here && (knob(ZV_MERGE_ALWAYS) != 0 || Lbatch / 246 >= 4L * n_cu) && Cp <= knob(ZV_MERGE_MAXC);
             if (fused && !whole_block && Cp == 64 && voc_.n_dil == 3 && kmax64 >= 3 && !dbg_here && (k64 < 0 || Lbatch / 244 >= 4L * n_cu))
             {
                 TripleJob tj[3];
@@ -1047,20 +1026,14 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 {
                     const ResPair *rp = &voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil];
                     if (rp[0].c1.K > kmax64 || !rp[0].r1 || !rp[0].r2 || !rp[1].r1 || !rp[1].r2 || !block64_supported(Cp, rp[0].c1.K, voc_.dil, 2)) continue;
-                    // (the merged launch must be the ring kernel's: only that takes the sum's first term from memory)
-                    const int ring = knob(ZV_PAIR64_RING);
-                    const bool full = jb == 0 && knob(ZV_BLOCK64_ALL) != 0 && merge_later && rp[2].r1 && rp[2].r2 &&
-                                      ring != 0 && (ring == 2 || 2 * (Lbatch / 246) >= 6L * n_cu) &&
-                                      block64_supported(Cp, rp[0].c1.K, voc_.dil, 3);
                     TripleJob &t = tj[nj++];
                     memset(&t, 0, sizeof(t));
                     t.y = ub;
-                    t.out = full ? y[jb] : (float *)xt[jb];
-                    t.n_dil = full ? 3 : 2;
+                    t.out = (float *)xt[jb];
+                    t.n_dil = 2;
                     t.Cp = Cp;
                     t.K = rp[0].c1.K;
                     t.slope = 0.1f;
-                    if (full) b64_full0 = true;
                     for (int d = 0; d < t.n_dil; d++)
                     {
                         t.w1[d] = rp[d].r1;
@@ -1072,7 +1045,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                         ff += conv_flops(La, C, C, rp[d].c1.K) + conv_flops(La, C, C, rp[d].c2.K);
                     }
                     b64[jb] = true;
-                    ycur[jb] = full ? y[jb] : (float *)xt[jb];
+                    ycur[jb] = (float *)xt[jb];
                 }
                 if (nj) ZV_LAUNCH("voc_resblock_conv", bb, ff, launch_block64(stream, tj, nj, fr, rate));
             }
@@ -1085,7 +1058,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             int npj = 0;                     // pair jobs of this dilation (the branches resblock_block64_kernel has not covered)
             for (int jb = 0; jb < 3; jb++)
             {
-                if (b64[jb] && (d < 2 || (jb == 0 && b64_full0))) continue;
+                if (b64[jb] && d < 2) continue;
                 const ResPair &rp = voc_.pairs[((size_t)i * voc_.n_rb + jb) * voc_.n_dil + d];
                 const float *yin = ycur[jb];
                 float *yout = fused ? ((d & 1) ? (float *)xt[jb] : y[jb]) : y[jb];
@@ -1142,7 +1115,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
             {
                 bool ms_free = true;
                 for (int q = 0; q < npj; q++) ms_free = ms_free && pj[0].out != pj[q].y;
-                float *ms = (ms_free && !(b64_full0 && pj[0].out == ycur[0])) ? pj[0].out : nullptr;
+                float *ms = ms_free ? pj[0].out : nullptr;
                 if (!ms) fail(ZV_ERR_DEVICE, "internal: no free buffer for the merged MRF sum");
                 if (Cp >= 256 && knob(ZV_MERGE_SEQ) != 0)
                 {
@@ -1160,7 +1133,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 }
                 else
                     ZV_LAUNCH("voc_resblock_conv", b1 + b2, f1 + f2,
-                              launch_pair(stream, pj, npj, n_cu, fr, rate, ms, b64_full0 ? ycur[0] : nullptr));
+                              launch_pair(stream, pj, npj, n_cu, fr, rate, ms));
                 merged_sum = ms;
             }
             else if (fused)
@@ -1234,7 +1207,7 @@ template <typename F> void Model::run_captured(int kind, const Batch &b, const v
     const void *kp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < nkey && i < 8; i++) kp[i] = key[i];
     for (auto &g : graphs_)
-        if (g.kind == kind && g.b.nseg == b.nseg && g.b.n_max == b.n_max && g.b.t_max == b.t_max && g.b.n_rows == b.n_rows &&
+        if (g.kind == kind && g.epoch == knob_epoch() && g.b.nseg == b.nseg && g.b.n_max == b.n_max && g.b.t_max == b.t_max && g.b.n_rows == b.n_rows &&
             g.b.t_rows == b.t_rows && g.b.d_tok == b.d_tok && g.b.d_frm == b.d_frm &&
             (b.d_tok || memcmp(&g.b.tok1, &b.tok1, sizeof(Seg)) == 0) && (b.d_frm || memcmp(&g.b.frm1, &b.frm1, sizeof(Seg)) == 0) &&
             memcmp(g.p, kp, sizeof(kp)) == 0)
@@ -1258,6 +1231,7 @@ template <typename F> void Model::run_captured(int kind, const Batch &b, const v
     ZV_HIP(hipStreamEndCapture(stream, &graph));
     CapturedGraph cg;
     cg.kind = kind;
+    cg.epoch = knob_epoch();       // a graph replays the kernel regime it was captured in: a later zv_debug_set captures anew
     cg.b = b;
     memcpy(cg.p, kp, sizeof(kp));
     hipError_t e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);

@@ -81,6 +81,7 @@ struct Batch
 struct CapturedGraph
 {
     int            kind = 0;               // 0 vocoder, 1 chain
+    unsigned       epoch = 0;              // knob_epoch() at capture
     Batch          b;
     const void    *p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipGraphExec_t exec = nullptr;
@@ -110,10 +111,12 @@ class Model
     // second stream + events for the waveform download of a finished group under the next group's kernels
     hipStream_t copy_stream();
     hipEvent_t  tail_event(int i);
-    // ordering of batches in flight on different lanes (ZV_LANE_ORDER): per lane the events "head done" (0) and "all kernels done" (1)
-    hipEvent_t  order_event(int lane, int which);
-    int         order_last_lane() const { return order_last_lane_; }
-    void        set_order_last_lane(int l) { order_last_lane_ = l; }
+    // Batches in flight (zv_synthesize_batch_begin) are numbered in the order they are enqueued; each owns a (start, done) pair
+    // of timing events on its lane's stream: `start` ahead of its upload, `done` behind its last kernel (zv_batch_timeline).
+    static constexpr int BATCH_RING = 64;
+    uint64_t    next_batch_seq() { return batch_seq_++; }
+    uint64_t    batch_seq() const { return batch_seq_; }
+    hipEvent_t  batch_event(uint64_t seq, int which);          // which: 0 start, 1 done
     int         tail_groups() const { return tail_groups_; }
     void decode_dev(const Batch &b, const float *d_hidden, const float *d_styles, float *d_mel);
     // taps are device pointers inside the arena (token rows as in ids), valid until the next call;
@@ -283,13 +286,12 @@ class Model
     void  *pinned_ = nullptr;
     size_t pinned_cap_ = 0;
     int  cur_lane_ = 0;
-    int  order_last_lane_ = -1;
-    std::vector<hipEvent_t> order_events_;
+    uint64_t   batch_seq_ = 0;
+    hipEvent_t batch_events_[2 * BATCH_RING] = {};
     void stash_lane();
 
     bool no_fuse_ = false;        // ZV_NO_FUSE=1: two launches per dilation pair (A/B measurement)
     bool no_triple_ = false;      // ZV_NO_TRIPLE=1: one launch per dilation pair also on the narrow stages (A/B measurement)
-    int  voc_group_ = 0;          // ZV_VOC_GROUP=G: utterances per vocoder pass of a batch (0 = all at once)
     int  tail_groups_ = 8;        // ZV_TAIL_GROUPS=G: utterance groups of a batch's last vocoder stage (0 / 1 = no split)
     bool skip_launch_ = false;    // vocode_group: the launches of the part that is not asked for are skipped
     hipStream_t copy_stream_ = nullptr;
