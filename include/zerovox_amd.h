@@ -203,10 +203,15 @@ zv_status zv_profile_end(zv_model *m, zv_kernel_stat *stats, uint32_t cap, uint3
  *   ZV_LAYER_DEC_ASR_RES   asr_res: conv 1x1 + InstanceNorm (src/stylettsdec.cpp:382-396): x [T][E] -> out [T][64]
  *   ZV_LAYER_DEC_TO_OUT    to_out: conv 1x1 + bias (src/stylettsdec.cpp:432-441): x [T][E] -> out [T][num_mels]
  *   ZV_LAYER_ENC_EMBED     word + punctuation embedding + positional encoding (src/fs2encoder.cpp:306-324): x [N][2] = (phoneme id,
- *                          punctuation id) as floats -> out [N][E] */
+ *                          punctuation id) as floats -> out [N][E]
+ *   ZV_LAYER_ENC_MHA       index l: MultiHeadAttention l alone, with its residual + LayerNorm (src/fs2encoder.cpp:71-140)
+ *   ZV_LAYER_ENC_FFN       index l: PositionwiseFeedForward l alone, with its residual + LayerNorm (src/fs2encoder.cpp:174-228)
+ *   ZV_LAYER_DEC_ADAIN     index 2 * b + (norm - 1): AdaIN1d norm1 / norm2 of AdainResBlk1d decode.b alone, with `style`
+ *                          (src/stylettsdec.cpp:171-200): x [T][C] -> out [T][C], C = the block's cin (norm1) / cout (norm2) */
 typedef enum { ZV_LAYER_VOC_RESBLOCK = 0, ZV_LAYER_ENC_FFT = 1, ZV_LAYER_DEC_BLOCK = 2, ZV_LAYER_VAR_PRED = 3,
                ZV_LAYER_VOC_UPSAMPLE = 4, ZV_LAYER_VOC_INPUT = 5, ZV_LAYER_VOC_OUTPUT = 6, ZV_LAYER_DEC_ASR_RES = 7,
-               ZV_LAYER_DEC_TO_OUT = 8, ZV_LAYER_ENC_EMBED = 9 } zv_layer_kind;
+               ZV_LAYER_DEC_TO_OUT = 8, ZV_LAYER_ENC_EMBED = 9, ZV_LAYER_ENC_MHA = 10, ZV_LAYER_ENC_FFN = 11,
+               ZV_LAYER_DEC_ADAIN = 12 } zv_layer_kind;
 zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint32_t rows, const float *style, float *out);
 
 /* ---- test / measurement switches (none is needed in production; no reference counterpart: the reference's only run-time

@@ -949,6 +949,19 @@ int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int col
         if (!rc) rc = ffn(c, y, rows, cols, index, ksz, out);
         free(y);
     }
+    else if (kind == ZVO_LAYER_ENC_MHA)                /* MultiHeadAttention `index` alone (src/fs2encoder.cpp:71-140, residual + LayerNorm included) */
+        rc = mha(c, x, rows, cols, index, H, out);
+    else if (kind == ZVO_LAYER_ENC_FFN)                /* PositionwiseFeedForward `index` alone (src/fs2encoder.cpp:174-228, residual + LayerNorm included) */
+        rc = ffn(c, x, rows, cols, index, ksz, out);
+    else if (kind == ZVO_LAYER_DEC_ADAIN)              /* AdaIN1d alone (src/stylettsdec.cpp:171-200): index = 2 * decode block + (norm - 1): [T][C] -> [T][C] */
+    {
+        if (index < 0 || index > 9) return fail("AdaIN %d", index);
+        float *xc = (float *)malloc((size_t)rows * cols * 4);
+        transpose(x, rows, cols, xc);
+        rc = adain1d(c, xc, cols, rows, style, E, index / 2, 1 + (index & 1));
+        if (!rc) transpose(xc, cols, rows, out);
+        free(xc);
+    }
     else if (kind == ZVO_LAYER_DEC_BLOCK)              /* 0,1: ResBlk1d encode.{0,1}; 2..6: AdainResBlk1d decode.{0..4}: [T][cin] -> [T][cout] */
     {
         const zvo_tensor *a0w = get(c, "_mel_decoder.asr_res.0.w");

@@ -89,7 +89,10 @@ enum { ZVO_LAYER_VOC_RESBLOCK = 0, ZVO_LAYER_ENC_FFT = 1, ZVO_LAYER_DEC_BLOCK = 
        ZVO_LAYER_VOC_OUTPUT = 6,     /* leaky_relu(0.01) + output conv k7 + tanh: [L][C] -> [L] (src/hifigan.cpp:324-345) */
        ZVO_LAYER_DEC_ASR_RES = 7,    /* asr_res conv 1x1 + InstanceNorm: [T][E] -> [T][64] (src/stylettsdec.cpp:382-396) */
        ZVO_LAYER_DEC_TO_OUT = 8,     /* to_out conv 1x1 + bias: [T][E] -> [T][80] (src/stylettsdec.cpp:432-441) */
-       ZVO_LAYER_ENC_EMBED = 9 };    /* word + punctuation embedding + positional encoding: [N][2] (id, punct as floats) -> [N][E] (src/fs2encoder.cpp:306-324) */
+       ZVO_LAYER_ENC_EMBED = 9,      /* word + punctuation embedding + positional encoding: [N][2] (id, punct as floats) -> [N][E] (src/fs2encoder.cpp:306-324) */
+       ZVO_LAYER_ENC_MHA = 10,       /* MultiHeadAttention `index` alone, with its residual + LayerNorm: [N][E] -> [N][E] (src/fs2encoder.cpp:71-140) */
+       ZVO_LAYER_ENC_FFN = 11,       /* PositionwiseFeedForward `index` alone, with its residual + LayerNorm (src/fs2encoder.cpp:174-228) */
+       ZVO_LAYER_DEC_ADAIN = 12 };   /* AdaIN1d alone, index = 2 * decode block + (norm - 1): [T][C] -> [T][C] (src/stylettsdec.cpp:171-200) */
 int zvo_layer(zvo_ctx *c, int kind, int index, const float *x, int rows, int cols, const float *style, int E, int H,
               const int *ksz, float *out);
 

@@ -170,6 +170,7 @@ class Oracle:
 
     LAYER_VOC_RESBLOCK, LAYER_ENC_FFT, LAYER_DEC_BLOCK, LAYER_VAR_PRED = 0, 1, 2, 3
     LAYER_VOC_UPSAMPLE, LAYER_VOC_INPUT, LAYER_VOC_OUTPUT, LAYER_DEC_ASR_RES, LAYER_DEC_TO_OUT, LAYER_ENC_EMBED = 4, 5, 6, 7, 8, 9
+    LAYER_ENC_MHA, LAYER_ENC_FFN, LAYER_DEC_ADAIN = 10, 11, 12
 
     def layer(self, kind: int, index: int, x: np.ndarray, out_cols: int, style=None, heads: int = 2, ksz=(9, 1),
               out_rows: Optional[int] = None) -> np.ndarray:

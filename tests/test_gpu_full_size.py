@@ -85,24 +85,17 @@ def test_config2_decoder_512_frames_vs_reference_golden(medium, fixture):
 
 @pytest.mark.parametrize("fixture", ["medium_T512_N64.npz", "medium_T512_N128.npz", "medium_T1024_N256.npz"])
 def test_config1_3_encoder_vs_reference_golden(medium, fixture):
-    """configs[0] (N=64) and configs[2] (N=128): integer decisions with near-tie accounting, pre-rounding taps close"""
+    """configs[0] (N=64), configs[2] (N=128), configs[3]'s longest utterance (N=256): float predictions and integer decisions
+    against the reference, gated on the fixture's own re-association floors with near-tie accounting"""
     from zerovox_cpp_amd import synth
     model, g, tensors = medium
     z = np.load(os.path.join(GOLD, fixture))
     T, N = int(z["T"]), int(z["N"])
     ids, puncts, style = synth.encoder_inputs(g, int(z["seed_enc"]), N)
     e = model.encode(ids, puncts, style, T)
-    ld_err = float(np.max(np.abs(e["logdur"] - z["logdur"])))
-    dur_g = (np.exp(e["logdur"].astype(np.float64)) - 1 + 0.5).astype(np.int64)
-    dur_r = (np.exp(z["logdur"].astype(np.float64)) - 1 + 0.5).astype(np.int64)
-    flips = int(np.sum(dur_g != dur_r))
-    pb = int(np.sum(e["pitch_bucket"] != z["pitch_bucket"]))
-    print(f"{fixture}: logdur err {ld_err:.3e}; duration flips {flips}/{N}; pitch-bucket flips {pb}/{N}; "
-          f"frames {e['n_frames']} vs {int(z['n_frames'])}")
-    assert ld_err <= 5e-3
-    assert np.max(np.abs(dur_g - dur_r)) <= 1 and flips <= max(2, N // 8)
-    assert np.max(np.abs(e["pitch_bucket"].astype(np.int64) - z["pitch_bucket"])) <= 1 and pb <= max(2, N // 4)
-    assert abs(e["n_frames"] - int(z["n_frames"])) <= flips
+    print(fixture)
+    from parity_helpers import encoder_decisions_vs_reference
+    encoder_decisions_vs_reference(e, z, g.ve_n_bins - 1, T)
     # zero tail behind the regulated frames, exactly
     assert not e["hidden"][e["n_frames"]:].any()
     assert e["hidden"][: e["n_frames"]].any()

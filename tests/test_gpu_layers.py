@@ -24,9 +24,10 @@ def env(ckpt):
 
 
 def teardown_module(module):
-    if "m" in _M:
-        _M["m"].close()
-        _M.clear()
+    for k in ("m", "mb"):
+        if k in _M:
+            _M[k].close()
+    _M.clear()
 
 
 def _rms(a):
@@ -176,3 +177,93 @@ def test_encoder_embedding_is_bit_exact(env):
     got = m.debug_layer(m.LAYER_ENC_EMBED, 0, x, g.E)
     ref = o.layer(o.LAYER_ENC_EMBED, 0, x, g.E)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2, 3])
+def test_attention_sublayer_and_feed_forward_sublayer_alone(env, layer):
+    """sub-block taps (round 4; the reference's tensor_dbg taps any node, src/utils.cpp:19-44): MultiHeadAttention alone (QKV,
+    softmax(QK^T / sqrt d) V, fc, residual + LayerNorm: src/fs2encoder.cpp:71-140) and PositionwiseFeedForward alone (conv k9 ->
+    ReLU -> conv k1, residual + LayerNorm: :174-228) — a regression in one of them no longer hides behind the other; both forms
+    of the attention kernel"""
+    from zerovox_cpp_amd import capi
+    m, g, t, o = env
+    x = np.random.default_rng(500 + layer).standard_normal((96, g.E)).astype(np.float32)
+    for sw in ({"ZV_ATT_SCALAR": 1}, {"ZV_ATT_MFMA": 1}):
+        with capi.switches(**sw):
+            got = m.debug_layer(m.LAYER_ENC_MHA, layer, x, g.E)
+        ref, alt = _oracle_pair(o, o.LAYER_ENC_MHA, layer, x, g.E, heads=g.encoder_head, ksz=g.conv_kernel_size)
+        _check(f"attention sublayer {layer} {list(sw)[0]}", got, ref, alt, 1e-4)
+    got = m.debug_layer(m.LAYER_ENC_FFN, layer, x, g.E)
+    ref, alt = _oracle_pair(o, o.LAYER_ENC_FFN, layer, x, g.E, heads=g.encoder_head, ksz=g.conv_kernel_size)
+    _check(f"feed-forward sublayer {layer}", got, ref, alt, 1e-4)
+    # the two taps chained are the whole block
+    y = m.debug_layer(m.LAYER_ENC_MHA, layer, x, g.E)
+    assert np.array_equal(m.debug_layer(m.LAYER_ENC_FFN, layer, y, g.E), m.debug_layer(m.LAYER_ENC_FFT, layer, x, g.E))
+
+
+@pytest.mark.parametrize("idx", list(range(10)))
+def test_every_adain_alone(env, idx):
+    """AdaIN1d alone (src/stylettsdec.cpp:171-200): gamma / beta from the production fc GEMM of all ten layers, the production
+    statistics, ((x - mean) * rstd) * (1 + gamma) + beta — without the activation and the conv it is fused into in the schedule"""
+    m, g, t, o = env
+    E, R = g.E, g.residual_dim
+    cin = [2 * E + R, 2 * E + R, 2 * E + R, E, E]
+    cout = [2 * E, 2 * E, E, E, E]
+    C = (cout if idx & 1 else cin)[idx // 2]
+    T = 96
+    x = (1.2 * np.random.default_rng(600 + idx).standard_normal((T, C)) + 0.3).astype(np.float32)
+    style = (0.05 * np.random.default_rng(8).standard_normal(E)).astype(np.float32)
+    got = m.debug_layer(m.LAYER_DEC_ADAIN, idx, x, C, style=style)
+    ref, alt = _oracle_pair(o, o.LAYER_DEC_ADAIN, idx, x, C, style=style)
+    _check(f"AdaIN decode.{idx // 2}.norm{1 + (idx & 1)} (C={C})", got, ref, alt, 1e-5, floor_mult=4.0)
+
+
+# ---- round 4: the same per-layer gates with the kernels only BATCHES pick forced on (a regression in a batch kernel then
+# ---- shows at its layer, against the reference semantics, instead of in a whole-vocoder RMS) --------------------------------
+BATCH_REGIME = dict(ZV_BLOCK64=-11, ZV_CONV_STREAM=2, ZV_CONV_GEMM=2, ZV_UP_GEMM=2, ZV_PAIR64_RING=2, ZV_TRIPLE_V2=3, ZV_FUSE256=1,
+                    ZV_PAIR_MT=0, ZV_DEC_PREPASS=1)
+
+
+def _batch_model(ckpt):
+    """a second model built with the regime on (ZV_FUSE256 is sampled when a model is loaded)"""
+    from zerovox_cpp_amd import capi
+    if "mb" not in _M:
+        with capi.switches(**BATCH_REGIME):
+            _M["mb"] = capi.Model(ckpt("medium")[0], 0)
+    return _M["mb"]
+
+
+@pytest.mark.parametrize("block", list(range(12)))
+def test_every_hifigan_residual_block_on_the_batch_kernels(env, ckpt, block):
+    """resblock_pair_kernel<256> (fused, 96-row tiles) / <128> / resblock_pair64_kernel (LDS weight ring) + resblock_block64_kernel
+    (two pairs per launch, every tap count) / resblock_block32_kernel on 512-row tiles, one residual block at a time vs the oracle;
+    and the bits of the default kernels"""
+    from zerovox_cpp_amd import capi
+    m, g, t, o = env
+    stage = block // 3
+    C, rate = m.voc_channels(stage), m.voc_rate(stage)
+    x = (0.5 * np.random.default_rng(100 + block).standard_normal((32 * rate, C))).astype(np.float32)
+    dflt = m.debug_layer(m.LAYER_VOC_RESBLOCK, block, x, C)
+    mb = _batch_model(ckpt)
+    with capi.switches(**BATCH_REGIME):
+        got = mb.debug_layer(mb.LAYER_VOC_RESBLOCK, block, x, C)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_RESBLOCK, block, x, C)
+    _check(f"hifigan block {block} (C={C}) batch kernels", got, ref, alt, 2e-4)
+    assert np.array_equal(got, dflt)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_every_transposed_conv_on_the_batch_kernels(env, idx):
+    """conv_gemm_kernel behind act_f16_kernel (the two deep upsample convs) / conv_stream_kernel (the two memory-bound ones)"""
+    from zerovox_cpp_amd import capi
+    m, g, t, o = env
+    cin = g.voc_channels >> idx
+    cout, s = cin // 2, g.upsample_scales[idx]
+    rate_in = 1 if idx == 0 else m.voc_rate(idx - 1)
+    x = (0.7 * np.random.default_rng(400 + idx).standard_normal((48 * rate_in, cin))).astype(np.float32)
+    dflt = m.debug_layer(m.LAYER_VOC_UPSAMPLE, idx, x, cout, out_rows=x.shape[0] * s)
+    with capi.switches(**BATCH_REGIME):
+        got = m.debug_layer(m.LAYER_VOC_UPSAMPLE, idx, x, cout, out_rows=x.shape[0] * s)
+    ref, alt = _oracle_pair(o, o.LAYER_VOC_UPSAMPLE, idx, x, cout, out_rows=x.shape[0] * s)
+    _check(f"conv_transpose1d {idx} batch kernels", got, ref, alt, 1e-4)
+    assert np.array_equal(got, dflt)

@@ -151,3 +151,37 @@ def test_a_switch_change_recaptures_graphs(models):
         model.set_graph_mode(False)
         model.device_free(d_mel)
         model.device_free(d_wav)
+
+
+def test_fused_tails_and_one_launch_regulator_give_the_same_bits(ckpt):
+    """round 4's launch savers for short utterances — LayerNorm launches that also do the style add / the predictor's linear
+    layer / the bucket + embedding step, scan + gather of the length regulator in one launch — change which launch does an
+    operation, never the operation: the bits of the plain schedule (ZV_LN_TAIL=0), eager and as a graph, for one utterance and
+    for a batch, every tap of the encoder included"""
+    from zerovox_cpp_amd import capi, synth
+    path, g, _ = ckpt("medium")
+    ids, puncts, style = synth.encoder_inputs(g, 61, 96)
+    T = 384
+    utts = [(*synth.encoder_inputs(g, 1600 + u, 30 + 9 * u), 200 + 16 * u) for u in range(6)]
+    ref = None
+    for name, sw in (("plain", dict(ZV_LN_TAIL=0)), ("default", {})):
+        with capi.switches(**sw):
+            m = capi.Model(path, 0)
+            outs = []
+            for graph in (False, True):
+                m.set_graph_mode(graph)
+                for rep in range(3 if graph else 1):
+                    w, nf = m.synthesize(ids, puncts, style, T)
+                    e = m.encode(ids, puncts, style, T)
+                    b = m.synthesize_batch(utts)
+                    outs.append((w, nf, e["hidden"], e["logdur"], e["pitch"], e["energy"], e["pitch_bucket"], e["energy_bucket"],
+                                 e["features"], [x[0] for x in b], [x[1] for x in b]))
+            m.close()
+        if ref is None:
+            ref = outs[0]
+        for o in outs:
+            assert o[1] == ref[1] and o[10] == ref[10], name
+            for a_, b_ in zip(o[:1] + o[2:9], ref[:1] + ref[2:9]):
+                assert np.array_equal(a_, b_), name
+            for a_, b_ in zip(o[9], ref[9]):
+                assert np.array_equal(a_, b_), name

@@ -687,7 +687,8 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
                 ZV_HIP(hipMemsetAsync(io, 0, (size_t)T * Mm * 4, M.stream));
             M.vocode_dev(zv::Batch::single(1, T, 1), (const float *)io, (float *)(io + al((size_t)T * Mm * 4)));
         }
-        else if (kind == ZV_LAYER_ENC_FFT || kind == ZV_LAYER_VAR_PRED || kind == ZV_LAYER_ENC_EMBED)
+        else if (kind == ZV_LAYER_ENC_FFT || kind == ZV_LAYER_VAR_PRED || kind == ZV_LAYER_ENC_EMBED || kind == ZV_LAYER_ENC_MHA ||
+                 kind == ZV_LAYER_ENC_FFN)
         {
             const uint32_t n = rows, T = 8;
             char *io = (char *)M.io_scratch(256 + 2 * al((size_t)n * 4) + al(E * 4) + (size_t)T * E * 4);
@@ -714,7 +715,7 @@ zv_status zv_debug_layer(zv_model *m, int kind, int index, const float *x, uint3
             ZV_HIP(hipMemcpyAsync(d_sty, sty, E * 4, hipMemcpyHostToDevice, M.stream));
             M.encode_dev(zv::Batch::single(n, T, n), d_ids, d_pun, d_sty, d_hid, d_nf);
         }
-        else if (kind == ZV_LAYER_DEC_BLOCK || kind == ZV_LAYER_DEC_ASR_RES || kind == ZV_LAYER_DEC_TO_OUT)
+        else if (kind == ZV_LAYER_DEC_BLOCK || kind == ZV_LAYER_DEC_ASR_RES || kind == ZV_LAYER_DEC_TO_OUT || kind == ZV_LAYER_DEC_ADAIN)
         {
             const uint32_t T = rows;
             check_T(M, T);

@@ -286,6 +286,16 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
 // y = LayerNorm(x + res) * w + b  over the C real channels (res may be null); channels [C, Cp) are zeroed
 hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp,
                                 const float *w, const float *b, float eps, float *y, int ldy, const Segs &segs);
+// the same LayerNorm with a tail in the same launch (short utterances: every launch is latency), each part optional:
+//   y += post[segment][:]                                   (post_seg: floats between segments' vectors)
+//   pred[row] = dot(y[row][:C], dot_w) + dot_b[0]           (launch_rowdot's chain)
+//   bucket[row] = clamp((int)(pred * (nbins - 1) + 0.5)); feat[row][:embC] += emb[bucket][:]   (launch_bucket_embed_add; needs dot_w)
+// layernorm_tail_ok(C): the tail exists in the rows-in-registers form only (C <= 768)
+bool       layernorm_tail_ok(int C);
+hipError_t launch_layernorm_tail(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp, const float *w,
+                                 const float *b, float eps, float *y, int ldy, const Segs &segs, const float *post, int post_seg,
+                                 const float *dot_w, const float *dot_b, float *pred, const float *emb, int nbins, int embC, float *feat,
+                                 int ldf, int32_t *bucket);
 // x[row][:] += v[segment][:]
 hipError_t launch_add_rowvec(hipStream_t s, float *x, int ld, int C, const float *v, int v_seg, const Segs &segs);
 // pred[n] = dot(x[n][:], w) + b

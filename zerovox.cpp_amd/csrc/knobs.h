@@ -35,7 +35,8 @@ namespace zv
     X(ZV_TRIPLE_DB, 1)         /* 0: one weight buffer for every branch */                                                            \
     X(ZV_TRIPLE_INTERLEAVE, 1) /* 0: branches not interleaved per XCD */                                                              \
     X(ZV_ATT_SCALAR, 0)        /* 1: scalar attention kernel */                                                                       \
-    X(ZV_ATT_MFMA, 0)          /* 1: matrix-core attention kernel whatever the size */
+    X(ZV_ATT_MFMA, 0)          /* 1: matrix-core attention kernel whatever the size */                                                \
+    X(ZV_LN_TAIL, 1)           /* 0: the style add, the predictors' linear layer and the bucket + embedding step as launches of their own instead of tails of a LayerNorm launch */
 
 // Diagnostic builds only (-DZV_DIAG: scripts/stamps*.py, ablation timings): switches that produce WRONG results or change
 // occupancy on purpose.  The shipped library does not contain them, nor the code they select (kernels.h: ZV_DBGBITS).

@@ -5,6 +5,8 @@
 #include "kernels.h"
 #include "knobs.h"
 
+#include <cstring>
+
 namespace zv
 {
 
@@ -917,10 +919,30 @@ hipError_t launch_attention(hipStream_t s, const float *q, const float *k, const
 // ---------------------------------------------------------------------------------------------------
 // y = LayerNorm(x + res) * w + b over channels: one wave per row (reference src/fs2encoder.cpp:132-137,
 // ggml_norm: mean and biased variance of (x - mean) accumulated in f64)
+// Optional tail (LnTail, all launch-count savers for short utterances — the same operations in the same order as the separate
+// kernels they replace, hence the same bits):
+//   post   : y += post[segment][c]            (features = encoder output + style_embed, reference src/fs2encoder.cpp:550-552)
+//   dot_w  : pred[row] = dot(y[row], dot_w) + dot_b[0]   (VariancePredictor linear_layer, :434-435; lane l sums channels l, l + 64, ...
+//            in that order and the wave sum follows: rowdot_kernel's chain)
+//   emb    : bucket[row] = clamp((int)((double)(pred * (nbins - 1)) + 0.5)); feat[row][:] += emb[bucket][:]   (:442-474, 565-569)
+struct LnTail
+{
+    const float *post;
+    int          post_seg;
+    const float *dot_w, *dot_b;
+    float       *pred;
+    const float *emb;
+    int          nbins, embC;
+    float       *feat;
+    int          ldf;
+    int32_t     *bucket;
+};
+
+template <bool TAIL>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, int ldx,
                                                             const float *__restrict__ res, int ldr, int C, int Cp,
                                                             const float *__restrict__ w, const float *__restrict__ b,
-                                                            float eps, float *__restrict__ y, int ldy, const Segs segs)
+                                                            float eps, float *__restrict__ y, int ldy, const Segs segs, const LnTail tail)
 {
     const Seg sg = seg_at(segs, blockIdx.y);
     const int rloc = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -937,6 +959,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
         // (every load unconditional at a clamped column, then selects: a load under a run-time condition becomes a branch with a
         // wait behind it — 24 + 24 exposed round trips per row in round 2's form of this loop, 12.5 us per launch)
         float v[LN_MAXE], rv[LN_MAXE], wv[LN_MAXE], bv[LN_MAXE];
+        float pv[TAIL ? LN_MAXE : 1], dv[TAIL ? LN_MAXE : 1];
+        // (the tail's vectors come with the other loads: unconditional, from a valid dummy vector where a part is absent)
+        const float *post = nullptr, *dotw = nullptr;
+        if constexpr (TAIL)
+        {
+            post = tail.post ? tail.post + (size_t)blockIdx.y * tail.post_seg : w;
+            dotw = tail.dot_w ? tail.dot_w : w;
+        }
 #pragma unroll
         for (int e = 0; e < LN_MAXE; e++)
         {
@@ -945,6 +975,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
             rv[e] = rr ? rr[cc] : 0.f;
             wv[e] = w[cc];
             bv[e] = b[cc];
+            if constexpr (TAIL)
+            {
+                pv[e] = post[cc];
+                dv[e] = dotw[cc];
+            }
         }
 #pragma unroll
         for (int e = 0; e < LN_MAXE; e++)
@@ -969,6 +1004,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
         s2 = wave_sum(s2);
         const float var = (float)(s2 / (double)C);
         const float scale = 1.0f / sqrtf(var + eps);
+        float dacc = 0.f;
+        const bool has_post = TAIL && tail.post != nullptr;
 #pragma unroll
         for (int e = 0; e < LN_MAXE; e++)
         {
@@ -977,10 +1014,33 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
             {
                 float t = (v[e] - mean) * scale;
                 t = wv[e] * t;
-                y[row * ldy + c] = t + bv[e];
+                t = t + bv[e];
+                if constexpr (TAIL)
+                {
+                    if (has_post) t = t + pv[e];
+                    dacc = fmaf(t, dv[e], dacc);
+                }
+                y[row * ldy + c] = t;
             }
         }
         for (int c = C + lane; c < Cp; c += 64) y[row * ldy + c] = 0.f;
+        if (TAIL && tail.dot_w)
+        {
+            dacc = wave_sum_f(dacc);
+            const float pr = dacc + tail.dot_b[0];
+            if (lane == 0) tail.pred[row] = pr;
+            if (tail.emb)
+            {
+                const int bin_max = tail.nbins - 1;
+                const float p = pr * (float)bin_max;
+                int yb = (int)((double)p + 0.5);          // truncating cast of x + 0.5 (double), not round-half-even
+                yb = yb < 0 ? 0 : (yb > bin_max ? bin_max : yb);
+                if (lane == 0) tail.bucket[row] = yb;
+                float *fr = tail.feat + row * tail.ldf;
+                const float *er = tail.emb + (size_t)yb * tail.embC;
+                for (int c = lane; c < tail.embC; c += 64) fr[c] = fr[c] + er[c];
+            }
+        }
         return;
     }
     double s = 0.0;
@@ -1008,8 +1068,37 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 hipError_t launch_add_layernorm(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp,
                                 const float *w, const float *b, float eps, float *y, int ldy, const Segs &segs)
 {
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((segs.max_rows + 3) / 4, segs.nseg), dim3(256), 0, s, x, ldx, res, ldr, C, Cp, w, b,
-                       eps, y, ldy, segs);
+    LnTail tail;
+    memset(&tail, 0, sizeof(tail));
+    hipLaunchKernelGGL(add_layernorm_kernel<false>, dim3((segs.max_rows + 3) / 4, segs.nseg), dim3(256), 0, s, x, ldx, res, ldr, C, Cp, w, b,
+                       eps, y, ldy, segs, tail);
+    return hipGetLastError();
+}
+
+bool layernorm_tail_ok(int C) { return C <= 64 * 12; }
+
+hipError_t launch_layernorm_tail(hipStream_t s, const float *x, int ldx, const float *res, int ldr, int C, int Cp, const float *w,
+                                 const float *b, float eps, float *y, int ldy, const Segs &segs, const float *post, int post_seg,
+                                 const float *dot_w, const float *dot_b, float *pred, const float *emb, int nbins, int embC, float *feat,
+                                 int ldf, int32_t *bucket)
+{
+    if (!layernorm_tail_ok(C)) return hipErrorInvalidValue;        // the tail lives in the rows-in-registers form
+    if (emb && (!dot_w || !feat || !bucket || nbins < 1)) return hipErrorInvalidValue;
+    if (dot_w && (!dot_b || !pred)) return hipErrorInvalidValue;
+    LnTail tail;
+    tail.post = post;
+    tail.post_seg = post_seg;
+    tail.dot_w = dot_w;
+    tail.dot_b = dot_b;
+    tail.pred = pred;
+    tail.emb = emb;
+    tail.nbins = nbins;
+    tail.embC = embC;
+    tail.feat = feat;
+    tail.ldf = ldf;
+    tail.bucket = bucket;
+    hipLaunchKernelGGL(add_layernorm_kernel<true>, dim3((segs.max_rows + 3) / 4, segs.nseg), dim3(256), 0, s, x, ldx, res, ldr, C, Cp, w, b,
+                       eps, y, ldy, segs, tail);
     return hipGetLastError();
 }
 
@@ -1167,10 +1256,88 @@ __global__ __launch_bounds__(256) void lr_gather16_kernel(const float *__restric
     }
 }
 
+// Scan and gather in ONE launch for utterances of at most 1 024 tokens: every workgroup (16 frames) recomputes its utterance's
+// rounded durations and their inclusive scan in LDS — a few hundred integer operations against a launch boundary — and the first
+// workgroup of a segment also stores the scan (the `cum` tap) and the frame count.  Integer sums: any scan order, the same values.
+__global__ __launch_bounds__(256) void lr_fused16_kernel(const float *__restrict__ feat, int ld, const float *__restrict__ logdur, int C,
+                                                         float *__restrict__ hidden, int ldh, int32_t *__restrict__ cum,
+                                                         int32_t *__restrict__ n_frames, const Segs tokens, const Segs frames)
+{
+    __shared__ int32_t lr_cs[1024];
+    __shared__ int32_t lr_part[256];
+    const Seg tk = seg_at(tokens, blockIdx.y), fr = seg_at(frames, blockIdx.y);
+    const int f0 = blockIdx.x * 16;
+    const int n = tk.rows, T = fr.rows;
+    if (f0 >= T) return;
+    const int nwalk = tk.aux < n ? tk.aux : n;
+    const int tid = threadIdx.x;
+    // four consecutive tokens per thread: durations (lr_scan_kernel's arithmetic), their running sums, the thread's total
+    int d[4], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        const int i = tid * 4 + j;
+        int v = 0;
+        if (i < nwalk)
+        {
+            const float dur = (float)(exp((double)logdur[tk.row0 + i]) - 1.0);
+            v = (int)((double)dur + 0.5);
+            if (v < 0) v = 0;
+            if (v > T) v = T;
+        }
+        tot += v;
+        d[j] = tot;
+    }
+    lr_part[tid] = tot;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1)
+    {
+        const int v = tid >= o ? lr_part[tid - o] : 0;
+        __syncthreads();
+        lr_part[tid] += v;
+        __syncthreads();
+    }
+    const int base = tid ? lr_part[tid - 1] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lr_cs[tid * 4 + j] = base + d[j];
+    __syncthreads();
+    if (blockIdx.x == 0)
+    {
+        for (int i = tid; i < n; i += 256) cum[tk.row0 + i] = lr_cs[i];
+        if (tid == 0)
+        {
+            const int total = lr_part[255];
+            n_frames[blockIdx.y] = total < T ? total : T;
+        }
+    }
+    const int f = f0 + (tid >> 4), l16 = tid & 15;
+    if (f >= T) return;
+    int lo = 0, hi = n;                  // first token i with cum[i] > f
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (lr_cs[mid] > f) hi = mid; else lo = mid + 1;
+    }
+    const bool live = lo < n;
+    const float4 *src = (const float4 *)(feat + ((size_t)tk.row0 + (live ? lo : 0)) * ld);
+    float4 *dst = (float4 *)(hidden + ((size_t)fr.row0 + f) * ldh);
+    for (int c4 = l16; c4 < (C >> 2); c4 += 16)
+    {
+        const float4 v = src[c4];
+        dst[c4] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 hipError_t launch_length_regulator(hipStream_t s, const float *feat, int ld, const float *logdur, int C, float *hidden,
                                    int ldh, int32_t *cum, int32_t *n_frames, const Segs &tokens, const Segs &frames)
 {
     if (tokens.nseg != frames.nseg || tokens.nseg < 1) return hipErrorInvalidValue;
+    if ((C & 3) == 0 && (ld & 3) == 0 && (ldh & 3) == 0 && tokens.max_rows >= 1 && tokens.max_rows <= 1024 && frames.max_rows >= 1)
+    {
+        hipLaunchKernelGGL(lr_fused16_kernel, dim3((frames.max_rows + 15) / 16, frames.nseg), dim3(256), 0, s, feat, ld, logdur, C, hidden,
+                           ldh, cum, n_frames, tokens, frames);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lr_scan_kernel, dim3(tokens.nseg), dim3(1024), 0, s, logdur, cum, n_frames, tokens, frames);
     if ((C & 3) == 0 && (ld & 3) == 0 && (ldh & 3) == 0 && (size_t)tokens.max_rows * 4 <= 48 * 1024 && tokens.max_rows >= 1)
         hipLaunchKernelGGL(lr_gather16_kernel, dim3((frames.max_rows + 15) / 16, frames.nseg), dim3(256), (size_t)tokens.max_rows * 4, s,

@@ -1017,7 +1017,7 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
         {
             const int k64 = knob(ZV_BLOCK64);
             const int kmax64 = k64 < 0 ? -k64 : k64;
-            if (fused && !whole_block && Cp == 64 && voc_.n_dil == 3 && kmax64 >= 3 && !dbg_here && (k64 < 0 || Lbatch / 244 >= 4L * n_cu))
+            if (fused && !whole_block && Cp == 64 && voc_.n_dil == 3 && kmax64 >= 3 && (k64 < 0 || Lbatch / 244 >= 4L * n_cu))
             {
                 TripleJob tj[3];
                 int nj = 0;
@@ -1426,6 +1426,24 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
         if (dbg_here) dbg_extract(out, ldo, b.cout, L);
     };
 
+    // AdaIN1d alone (sub-block tap, ZV_LAYER_DEC_ADAIN; index = 2 * decode block + (norm - 1); reference src/stylettsdec.cpp:171-200):
+    // the production fc GEMM above, the production statistics (partial sums + finalise) and the prologue's arithmetic
+    // ((x - mean) * rstd) * gamma + beta written out by norm_apply_kernel — no activation, no conv
+    if (dbg_layer.kind == ZV_LAYER_DEC_ADAIN)
+    {
+        const int bi = dbg_layer.index / 2, k = dbg_layer.index & 1;
+        if (bi < 0 || bi >= 5) return;
+        const DecBlk &b = dec_.dec[bi];
+        const int Cn = k ? b.cout : b.cin, go = k ? b.g2 : b.g1;
+        float *xin = cat;                                  // [L][Cn] with leading dimension Cn: any buffer of L * CAT floats
+        dbg_inject(xin, Cn, Cn, L);
+        ZV_HIP(launch_stats_partial(stream, xin, Cn, Cn, part_o, nblk, fr, 1));
+        ZV_HIP(launch_stats_finalize(stream, part_o, nblk, Cn, 1e-5f, st_x, ss, 0, fr, 1));
+        ZV_HIP(launch_norm_apply(stream, xin, Cn, Cn, st_x, ss, h + go, h + go + Cn, t1, Cn, nullptr, nblk, fr));
+        dbg_extract(t1, Cn, Cn, L);
+        return;
+    }
+
     // encode0 / encode1: ResBlk1d with affine InstanceNorm                         (src/stylettsdec.cpp:69-149,373-374)
     block(dec_.enc[0], d_hidden, Ed, Ed, st_x, dec_.enc[0].n1w, dec_.enc[0].n1b, dec_.enc[0].n2w, dec_.enc[0].n2b, 0, x0, B, true);
     block(dec_.enc[1], x0, B, B, st_y, dec_.enc[1].n1w, dec_.enc[1].n1b, dec_.enc[1].n2w, dec_.enc[1].n2b, 0, cat, CAT, true);
@@ -1504,6 +1522,9 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
     _Float16 *hh = arena_.take_n<_Float16>(n * Fp);
     const int Vp = round_up(enc_.dur.V, 16);
     float *va = arena_.take_n<float>(n * Vp), *vb = arena_.take_n<float>(n * Vp);
+    // LayerNorm launches that carry tail work (kernels.h: launch_layernorm_tail): the style add, the predictors' linear layer, the
+    // bucket + embedding step — 6 launches fewer per call, same operations in the same order (ZV_LN_TAIL = 0: separate launches)
+    const bool tails = dbg_layer.kind < 0 && knob(ZV_LN_TAIL) != 0 && layernorm_tail_ok(Ed) && layernorm_tail_ok(enc_.dur.V);
     EncoderTaps t;
     t.features = x;
     t.logdur = arena_.take_n<float>(n);
@@ -1526,8 +1547,12 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
     for (const EncLayer &Ly : enc_.layers)
     {
         const bool dbg_here = dbg_layer.kind == 1 && dbg_layer.index == layer_no;
+        // sub-block taps (the reference's tensor_dbg taps any node, src/utils.cpp:19-44): the attention sublayer alone
+        // (ZV_LAYER_ENC_MHA: x -> y) and the conv feed-forward sublayer alone (ZV_LAYER_ENC_FFN: y -> x)
+        const bool dbg_mha = dbg_layer.kind == ZV_LAYER_ENC_MHA && dbg_layer.index == layer_no;
+        const bool dbg_ffn = dbg_layer.kind == ZV_LAYER_ENC_FFN && dbg_layer.index == layer_no;
         layer_no++;
-        if (dbg_here) dbg_inject(x, Ed, Ed, n);
+        if (dbg_here || dbg_mha) dbg_inject(x, Ed, Ed, n);
         ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * nd * Ed), 6.0 * nd * Ed * Ed,
                   launch_linear(stream, x, Ed, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr, tk));
         ZV_LAUNCH("enc_attention", 16.0 * nd * Ed, 4.0 * nd * bt.n_max * Ed,
@@ -1536,6 +1561,12 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
                   launch_linear(stream, o, Ed, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr, tk));
         ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
                   launch_add_layernorm(stream, f, Ed, x, Ed, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed, tk));
+        if (dbg_mha)
+        {
+            dbg_extract(y, Ed, Ed, n);
+            return t;
+        }
+        if (dbg_ffn) dbg_inject(y, Ed, Ed, n);
         {   // FFN: conv k9 + b -> relu (kept as f16 operand) -> conv k1 + b            (src/fs2encoder.cpp:190-214)
             ConvJob a = job(Ly.w1);
             a.x0 = y;
@@ -1550,19 +1581,29 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
             b.out = f;
             conv(&b, 1, tk, 1, "enc_conv", conv_bytes(nd, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(nd, Ly.w1.Cout, Ed, Ly.w2.K));
         }
-        ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
-                  launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk));
-        if (dbg_here)
+        // (the last layer's LayerNorm also adds the style vector: features = encoder output + style_embed, :550-552)
+        if (tails && layer_no == (int)enc_.layers.size())
+            ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 9.0 * nd * Ed,
+                      launch_layernorm_tail(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk, d_styles, Ed, nullptr, nullptr,
+                                            nullptr, nullptr, 0, 0, nullptr, 0, nullptr));
+        else
+            ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
+                      launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk));
+        if (dbg_here || dbg_ffn)
         {
             dbg_extract(x, Ed, Ed, n);
             return t;
         }
     }
     // features = encoder output + style_embed                                             (:550-552)
-    ZV_LAUNCH("enc_add_style", 8.0 * nd * Ed, 1.0 * nd * Ed, launch_add_rowvec(stream, x, Ed, Ed, d_styles, Ed, tk));
+    if (!(tails && !enc_.layers.empty()))
+        ZV_LAUNCH("enc_add_style", 8.0 * nd * Ed, 1.0 * nd * Ed, launch_add_rowvec(stream, x, Ed, Ed, d_styles, Ed, tk));
 
     int pred_no = 0;
-    auto predictor = [&](const VarPred &v, float *out) {        // VariancePredictor::graph (:386-440)
+    // VariancePredictor::graph (:386-440): conv + relu, LayerNorm, conv + relu, LayerNorm, linear.  `emb` (pitch / energy): the
+    // prediction's bucket and x += embedding[bucket] (:442-474, 565-569) follow.  With `tails` the second LayerNorm's launch also
+    // does the linear layer and the bucket / embedding step (5 + 1 launches -> 4).
+    auto predictor = [&](const VarPred &v, float *out, const float *emb, int32_t *bucket) {
         const bool dbg_here = dbg_layer.kind == 3 && dbg_layer.index == pred_no && !dbg_layer.done;
         pred_no++;
         if (dbg_layer.done) return;
@@ -1582,20 +1623,26 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
         b.oslope = 0.f;
         b.out = va;
         conv(&b, 1, tk, 1, "enc_conv", conv_bytes(nd, v.V, v.V, 3, false), conv_flops(nd, v.V, v.V, 3));
+        if (tails)
+        {
+            ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V + (emb ? 12.0 * nd * Ed : 0.0), 10.0 * nd * v.V,
+                      launch_layernorm_tail(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tk, nullptr, 0, v.lw, v.lb, out,
+                                            emb, (int)hp.encoder_ve_n_bins, Ed, x, Ed, bucket));
+            return;
+        }
         ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
                   launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tk));
         ZV_LAUNCH("enc_rowdot", 4.0 * nd * v.V, 2.0 * nd * v.V, launch_rowdot(stream, vb, Vp, v.V, v.lw, v.lb, out, tk));
         if (dbg_here) dbg_extract(out, 1, 1, n);
+        if (emb && !dbg_layer.done)
+            ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
+                      launch_bucket_embed_add(stream, out, hp.encoder_ve_n_bins, emb, Ed, x, Ed, bucket, tk));
     };
-    predictor(enc_.dur, t.logdur);
-    predictor(enc_.pitch, t.pitch);
+    predictor(enc_.dur, t.logdur, nullptr, nullptr);
+    predictor(enc_.pitch, t.pitch, enc_.pitch_emb, t.pitch_bucket);
     if (dbg_layer.done) return t;
-    ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
-              launch_bucket_embed_add(stream, t.pitch, hp.encoder_ve_n_bins, enc_.pitch_emb, Ed, x, Ed, t.pitch_bucket, tk));
-    predictor(enc_.energy, t.energy);                           // sees the pitch-augmented features (:569-572)
+    predictor(enc_.energy, t.energy, enc_.energy_emb, t.energy_bucket);      // sees the pitch-augmented features (:569-572)
     if (dbg_layer.done) return t;
-    ZV_LAUNCH("enc_bucket_embed", 12.0 * nd * Ed, 1.0 * nd * Ed,
-              launch_bucket_embed_add(stream, t.energy, hp.encoder_ve_n_bins, enc_.energy_emb, Ed, x, Ed, t.energy_bucket, tk));
     ZV_LAUNCH("enc_length_regulator", 4.0 * (nd + (double)bt.t_rows) * Ed, 0.0,
               launch_length_regulator(stream, x, Ed, t.logdur, Ed, d_hidden, Ed, t.cum, d_nframes, tk, fr));
     return t;
