@@ -1468,6 +1468,317 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same fused dilation pair on v_mfma_f32_16x16x32_f16 (round 4).
+//
+// The two f16 MFMA shapes give the SAME BITS for one k-ordered accumulation chain: a chain walked 16 products per instruction
+// (32x32x16) equals the same chain walked 32 per instruction (16x16x32) — measured on 204 800 random elements at three scales,
+// scripts/mfma_shape_bits.hip: 0 differ (neither equals a sequential fma chain nor an f64 sum rounded once: the matrix core has
+// its own order, but one order for both shapes).  So a kernel may change its shape without leaving the family's "every output
+// element is ONE chain over (chunk, tap, channel)" contract, and the chip holds a higher clock under the 16 x 16 shape
+// (MI355X_MICROARCH.md, DVFS give-back item 7).  One step here = 32 channels of one tap = two steps of the kernel above:
+//   LDS side   l[mt][lt]: the two 16-row tiles of 32-row block mt.  Fragment row c of tile lt is block row 2c + lt (even / odd
+//              interleave): with the tile's row stride 2 CP + 16 bytes the ds_read_b128 of lane (c, g = k group) then falls on
+//              16 distinct 16-byte slots per lane group (rows c and 16 + c would share a slot: 2-way);
+//   weights    w[nt][wt]: the two 16-channel tiles of output tile nt, packed in fragment order by pack_pair_weight16 (conv1: the
+//              A operand, row r of tile wt = channel 16 wt + r; conv2: the B operand, column c of tile wt = channel 2c + wt, so a
+//              lane's two tiles are NEIGHBOURING channels and the epilogue moves 8 bytes per lane: four rows x 128 bytes per
+//              instruction, half the instructions of the 4-byte column accesses above).
+// acc[mt][nt][wt][lt] is a 16 x 16 tile: conv1 (weights as A) lane (c, g) holds channels 16 wt + 4g + i of time row 2c + lt;
+// conv2 holds time rows 8g + 2i + lt of channel 2c + wt.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+size_t pair_weight16_halfs(int Cp, int K) { return pair_weight_halfs(Cp, K); }
+
+// conv2_layout: the B-operand form (channel 2c + wt); else the A-operand form (channel 16 wt + r)
+void pack_pair_weight16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout)
+{
+    const int nk2 = Cp / 32;
+    const size_t seg = (size_t)(round_up(K * (Cp / 16), 4) + 8) * 512;
+    memset(dst, 0, pair_weight16_halfs(Cp, K) * 2);
+    for (int nt = 0; nt < Cp / 32; nt++)
+        for (int tap = 0; tap < K; tap++)
+            for (int k2 = 0; k2 < nk2; k2++)
+                for (int wt = 0; wt < 2; wt++)
+                {
+                    uint16_t *d = dst + nt * seg + ((size_t)(tap * nk2 + k2) * 2 + wt) * 512;
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++)
+                        {
+                            const int r = lane & 15, g = lane >> 4;
+                            const int oc = nt * 32 + (conv2_layout ? 2 * r + wt : 16 * wt + r), ic = k2 * 32 + 8 * g + j;
+                            d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                        }
+                }
+}
+
+template <int MT, int NT, bool SWAP, bool ZERO = false>
+__device__ __forceinline__ void mfma16_step(floatx4 (&acc)[MT][NT][2][2], const half8 (&l)[MT][2], const half8 (&w)[NT][2])
+{
+    const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int wt = 0; wt < 2; wt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+                {
+                    if constexpr (SWAP)      // weights as the A operand -> D[oc][time]
+                        acc[mt][nt][wt][lt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[nt][wt], l[mt][lt], ZERO ? z : acc[mt][nt][wt][lt], 0, 0, 0);
+                    else
+                        acc[mt][nt][wt][lt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l[mt][lt], w[nt][wt], ZERO ? z : acc[mt][nt][wt][lt], 0, 0, 0);
+                }
+}
+
+// the first two steps' weight fragments of a contraction (see deep_preload_b)
+template <int NT>
+__device__ __forceinline__ void deep16_preload_b(half8 (&b0)[2][NT][2], const half8 *wq, size_t wseg)
+{
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int wt = 0; wt < 2; wt++) b0[u][nt][wt] = wq[nt * wseg + (u * 2 + wt) * 64];
+}
+
+// mfma_taps_deep's structure in steps of 32 channels: a body = 4 steps (= its 8), the weight fragments in two ping-pong sets of
+// two steps each (requested a set ahead), the LDS fragments one step ahead through a ring of four register sets, a scheduling
+// fence per step.  Same (tap, channel) order: the same chain per output element.
+template <int CP, int MT, int NT, bool SWAP>
+__device__ __forceinline__ void mfma16_taps_deep(floatx4 (&acc)[MT][NT][2][2], const char *ap, int dilRS, const half8 *wq, size_t wseg, int K,
+                                                 half8 (&b0)[2][NT][2])
+{
+    constexpr int RS = CP * 2 + 16, NK2 = CP / 32;
+    constexpr int TPB = (NK2 >= 4) ? 1 : 4 / NK2;        // taps per body: 4 / 2 / 1 / (1/2) for CP = 32 / 64 / 128 / 256
+    constexpr bool HALF = NK2 == 8;                      // CP = 256: a tap is two bodies
+    const int nsb = (K * NK2 + 1) >> 1;                  // 2-step sub-blocks (the last one may run partly on zero weights)
+    const int nb = nsb >> 1;
+    half8 b1[2][NT][2];
+    wq += 4 * 64;
+    half8 a[4][MT][2];
+#define ZV16_UN(un) ((un) >= 4 ? (un) - 4 : 0)
+#define ZV16_A_ADDR(un) ((un) >= 4 ? tbn[(ZV16_UN(un) / NK2) % 4] + (ZV16_UN(un) % NK2) * 64 : tb[((un) / NK2) % 4] + ((un) % NK2) * 64)
+#define ZV16_LOAD_A(un)                                                                                          \
+    {                                                                                                            \
+        const char *np_ = ZV16_A_ADDR(un);                                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                        \
+            _Pragma("unroll") for (int lt = 0; lt < 2; lt++) a[(un) % 4][mt][lt] = *(const half8 *)(np_ + (mt * 32 + lt) * RS); \
+    }
+#define ZV16_STEP(u, bset) ZV16_LOAD_A((u) + 1) mfma16_step<MT, NT, SWAP>(acc, a[(u) % 4], bset[(u) % 2]); __builtin_amdgcn_sched_barrier(0);
+#define ZV16_STEPZ(u, bset) ZV16_LOAD_A((u) + 1) mfma16_step<MT, NT, SWAP, true>(acc, a[(u) % 4], bset[(u) % 2]); __builtin_amdgcn_sched_barrier(0);
+#define ZV16_BODY(FIRSTSTEP)                                                                                     \
+    {                                                                                                            \
+        const char *tb[4], *tbn[4];                                                                              \
+        tb[0] = ap;                                                                                              \
+        _Pragma("unroll") for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;                   \
+        const char *apn = HALF ? ((ib & 1) ? ap + (dilRS - 256) : ap + 256) : ap + TPB * dilRS; /* next body */  \
+        tbn[0] = apn;                                                                                            \
+        _Pragma("unroll") for (int x = 1; x < 4; x++) tbn[x] = (x < TPB) ? apn + x * dilRS : apn;                \
+        _Pragma("unroll") for (int u = 0; u < 2; u++)                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                    \
+                _Pragma("unroll") for (int wt = 0; wt < 2; wt++) b1[u][nt][wt] = wq[nt * wseg + (u * 2 + wt) * 64];        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        FIRSTSTEP(0, b0) ZV16_STEP(1, b0)                                                                        \
+        _Pragma("unroll") for (int u = 0; u < 2; u++)                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                    \
+                _Pragma("unroll") for (int wt = 0; wt < 2; wt++) b0[u][nt][wt] = wq[nt * wseg + (4 + u * 2 + wt) * 64];    \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        ZV16_STEP(2, b1) ZV16_STEP(3, b1)                                                                        \
+        ap = apn;                                                                                                \
+        wq += 8 * 64;                                                                                            \
+    }
+    {
+        const char *tb[4], *tbn[4];
+        tb[0] = ap;
+#pragma unroll
+        for (int x = 1; x < 4; x++) tb[x] = (x < TPB) ? ap + x * dilRS : ap;
+#pragma unroll
+        for (int x = 0; x < 4; x++) tbn[x] = ap;
+        ZV16_LOAD_A(0)
+    }
+    {
+        const int ib = 0;
+        ZV16_BODY(ZV16_STEPZ)
+    }
+    for (int ib = 1; ib < nb; ib++) ZV16_BODY(ZV16_STEP)
+    if constexpr (CP == 64)
+        if (nsb & 1)                             // odd sub-block count (K = 3 mod 4 taps): one more tap on b0
+        {
+            const char *tb[4] = {ap, ap, ap, ap};
+            const char *tbn[4] = {ap, ap, ap, ap};
+            (void)tbn;
+            ZV16_STEP(0, b0) ZV16_STEP(1, b0)
+        }
+#undef ZV16_BODY
+#undef ZV16_STEPZ
+#undef ZV16_STEP
+#undef ZV16_LOAD_A
+#undef ZV16_A_ADDR
+#undef ZV16_UN
+}
+
+template <int CP, int MT, bool MERGE>
+__global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairJobs jobs)
+{
+    constexpr int NT = (CP == 256) ? 2 : 1;            // output tiles of 32 channels per wave
+    constexpr int WN = CP / 32 / NT, WM = 4 / WN;
+    constexpr int BM = 32 * MT * WM;
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+    floatx4 msum[MERGE ? MT : 1][MERGE ? NT : 1][2][2];
+    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
+    {
+    const PairJob &P = jobs.j[jb];
+    const int K = P.K, dil = P.dil;
+    const int h2 = (K - 1) / 2, h1 = h2 * dil;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
+    if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the LDS tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lc = lane & 15, lg = lane >> 4;
+    const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;        // half8 units per n-tile segment
+
+    // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+    constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : (CP == 128 ? ZV_STAGE_U128 : ZV_STAGE_U256)));
+    constexpr bool EARLY_B = CP <= 64 && !MERGE;
+    half8 bw[2][NT][2];
+    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg);
+    stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+    __syncthreads();
+
+    // this lane's fragment rows: block row 2c (+ lt) of the wave's 32-row blocks, k group g
+    const char *abase = smem + (wm * 32 * MT + 2 * lc) * RS + lg * 16;
+    floatx4 acc[MT][NT][2][2];
+
+    // ---- conv1 (dilated), transposed product: acc[mt][nt][wt][lt][i] = xt_pre[time = mt*32 + 2c + lt][oc = 16 wt + 4g + i]
+    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg);
+    mfma16_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg, K, bw);
+    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
+    __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
+
+    // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
+    {
+        const float sl = P.slope;
+        const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+        {
+            const int ocb = (wn * NT + nt) * 32;
+            float4 bq[2];
+#pragma unroll
+            for (int wt = 0; wt < 2; wt++) bq[wt] = *(const float4 *)(P.b1 + ocb + 16 * wt + 4 * lg);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+                {
+                    const int i = wm * 32 * MT + mt * 32 + 2 * lc + lt;
+                    const int t = t0 - h2 + i;
+                    const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                    for (int wt = 0; wt < 2; wt++)
+                    {
+                        half4 h;
+                        h[0] = (_Float16)lrelu_max(acc[mt][nt][wt][lt][0] + bq[wt].x, sl);
+                        h[1] = (_Float16)lrelu_max(acc[mt][nt][wt][lt][1] + bq[wt].y, sl);
+                        h[2] = (_Float16)lrelu_max(acc[mt][nt][wt][lt][2] + bq[wt].z, sl);
+                        h[3] = (_Float16)lrelu_max(acc[mt][nt][wt][lt][3] + bq[wt].w, sl);
+                        uint2 pk = *(uint2 *)&h;
+                        if (edge)
+                        {
+                            pk.x = in ? pk.x : 0u;
+                            pk.y = in ? pk.y : 0u;
+                        }
+                        *(uint2 *)(smem + i * RS + (ocb + 16 * wt + 4 * lg) * 2) = pk;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
+    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg);
+    mfma16_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg, K, bw);
+
+    // ---- epilogue: out = y + (conv2 + b2).  acc[mt][nt][wt][lt][i] = time row mt*32 + 8g + 2i + lt, channel 2c + wt: the lane's two
+    // weight tiles are neighbouring channels -> 8-byte accesses, four rows x 128 bytes per instruction.  Buffer descriptors over
+    // exactly this tile's valid rows: row >= TM or time >= L is out of range (loads give 0, stores are dropped).
+    const int nrows = (L - t0 < TM) ? (L - t0) : TM;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    float *const outp = (!MERGE && P.sum_out) ? P.sum_out + (size_t)sg.row0 * jobs.rate * CP : out_seg;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(outp + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sum = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((P.sum_in ? P.sum_in : y_seg) + (P.sum_in ? (size_t)sg.row0 * jobs.rate * CP : 0) + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+    {
+        const int oc = (wn * NT + nt) * 32 + 2 * lc;
+        const float2 bias = *(const float2 *)(P.b2 + oc);
+        const int voff = ((wm * 32 * MT + 8 * lg) * CP + oc) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+        {
+            u32x2 resv[2][4];
+#pragma unroll
+            for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    resv[lt][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, (mt * 32 + 2 * i + lt) * CP * 4, 0);
+            u32x2 sumv[2][4];
+            if (!MERGE && P.sum_out && P.sum_in)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        sumv[lt][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_sum, voff, (mt * 32 + 2 * i + lt) * CP * 4, 0);
+#pragma unroll
+            for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    float v0 = (acc[mt][nt][0][lt][i] + bias.x) + __uint_as_float(resv[lt][i][0]);
+                    float v1 = (acc[mt][nt][1][lt][i] + bias.y) + __uint_as_float(resv[lt][i][1]);
+                    if constexpr (MERGE)
+                    {
+                        msum[mt][nt][0][lt][i] = jb == 0 ? v0 : msum[mt][nt][0][lt][i] + v0;
+                        msum[mt][nt][1][lt][i] = jb == 0 ? v1 : msum[mt][nt][1][lt][i] + v1;
+                        if (jb != jobs.njobs - 1) continue;
+                        v0 = msum[mt][nt][0][lt][i];
+                        v1 = msum[mt][nt][1][lt][i];
+                    }
+                    else if (P.sum_out && P.sum_in)
+                    {
+                        // this branch's term of the MRF sum: sum_out = sum_in + v (the first branch stores v itself)
+                        v0 = __uint_as_float(sumv[lt][i][0]) + v0;
+                        v1 = __uint_as_float(sumv[lt][i][1]) + v1;
+                    }
+                    const u32x2 o = {__float_as_uint(v0), __float_as_uint(v1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, (mt * 32 + 2 * i + lt) * CP * 4, ZV_ST_AUX);
+                }
+        }
+    }
+    }
+}
+
 #ifdef ZV_STAMPS
 extern "C" int zv_debug_read_stamps(unsigned long long *out, size_t n)
 {
@@ -2084,14 +2395,19 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
 #ifdef ZV_DIAG
     lds += (size_t)knob(ZV_LDS_PAD);       // diagnostic build: extra bytes of LDS per workgroup = a lower occupancy on purpose
 #endif
-    auto kern = resblock_pair_kernel<CP, MT, MERGE>;
-    if (lds > 64 * 1024)
-    {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
-    return hipGetLastError();
+    // the 16 x 16 x 32 form (same bits, a higher clock under load) wherever its weight copies exist; ZV_PAIR16 = 0: the 32 x 32 x 16 form
+    bool x16 = knob(ZV_PAIR16) != 0;
+    for (int i = 0; i < njobs; i++) x16 = x16 && js.j[i].w1x && js.j[i].w2x;
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+        return hipGetLastError();
+    };
+    return x16 ? launch(resblock_pair16_kernel<CP, MT, MERGE>) : launch(resblock_pair_kernel<CP, MT, MERGE>);
 }
 
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)

@@ -163,6 +163,7 @@ struct PairJob
     float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
     const void  *w1, *w2;    // packed by pack_pair_weight (zero-padded per-tile segments)
     const void  *w1r, *w2r;  // packed by pack_pair_weight_ring ([tap][kc][ntile] fragments), or null
+    const void  *w1x, *w2x;  // packed by pack_pair_weight16 (conv1: A-operand form, conv2: B-operand form) for resblock_pair16_kernel, or null
     const float *b1, *b2;
     int          L, Cp, K, dil;
     float        slope;
@@ -190,6 +191,9 @@ bool       pair_supported(int Cp, int K);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
+// the same weight in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair16_kernel); conv2_layout: the conv's second layer
+size_t     pair_weight16_halfs(int Cp, int K);
+void       pack_pair_weight16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout);
 // the same weight as the stream resblock_pair64_kernel moves through its LDS ring: [tap][kc][ntile][lane][8 halfs]
 size_t     pair_ring_weight_halfs(int Cp, int K);
 void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);

@@ -268,6 +268,13 @@ Model::Model(const std::string &path, int dev) : device(dev)
                         pack_pair_weight((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, pk.data());
                         *dst[q] = dev_alloc(pk.size() * 2 + 8192);
                         ZV_HIP(hipMemcpy(*dst[q], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+                        {   // the same weights in 16 x 16 x 32 fragment order (resblock_pair16_kernel): conv1 as the A operand, conv2 as B
+                            std::vector<uint16_t> xk(pair_weight16_halfs(rp.c1.Cout_p, rp.c1.K));
+                            pack_pair_weight16((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, xk.data(), q == 1);
+                            void **xd = q ? &rp.x2 : &rp.x1;
+                            *xd = dev_alloc(xk.size() * 2 + 8192);
+                            ZV_HIP(hipMemcpy(*xd, xk.data(), xk.size() * 2, hipMemcpyHostToDevice));
+                        }
                         if (rp.c1.Cout_p == 64)
                         {
                             std::vector<uint16_t> rk(pair_ring_weight_halfs(64, rp.c1.K));
@@ -1091,6 +1098,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 p.w2 = rp.p2;
                 p.w1r = rp.r1;
                 p.w2r = rp.r2;
+                p.w1x = rp.x1;
+                p.w2x = rp.x2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
                 p.Cp = Cp;
