@@ -2079,6 +2079,254 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     }
 }
 
+// the ring stream in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair64x_kernel / resblock_block64x_kernel): [tap][step of 32
+// channels][ntile][wt][lane][8 halfs]; conv2_layout as in pack_pair_weight16
+void pack_pair_weight_ring16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout)
+{
+    const int nk2 = Cp / 32, nnt = Cp / 32;
+    for (int tap = 0; tap < K; tap++)
+        for (int k2 = 0; k2 < nk2; k2++)
+            for (int nt = 0; nt < nnt; nt++)
+                for (int wt = 0; wt < 2; wt++)
+                {
+                    uint16_t *d = dst + ((((size_t)(tap * nk2 + k2) * nnt + nt) * 2) + wt) * 512;
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++)
+                        {
+                            const int r = lane & 15, g = lane >> 4;
+                            const int oc = nt * 32 + (conv2_layout ? 2 * r + wt : 16 * wt + r), ic = k2 * 32 + 8 * g + j;
+                            d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                        }
+                }
+}
+
+template <bool MERGE>
+__global__ __launch_bounds__(256, 2) void resblock_pair64x_kernel(const PairJobs jobs)
+{
+    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
+    constexpr int CHUNK = 8 * 1024;                  // one tap: 4 channel steps x 2 output tiles
+    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
+    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+
+#ifdef ZV_STAMPS
+    const int stamp_wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
+    {
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 9] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+    }
+#endif
+    ZV_STAMP(0)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char *ring = smem + jobs.ring_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lg = lane >> 4;
+    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair16_kernel)
+    const char *bl = ring + lane * 16;
+
+    floatx4 msum[MERGE ? MT : 1][MERGE ? NT : 1][2][2];
+    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
+    {
+        const PairJob &P = jobs.j[jb];
+        const int K = P.K, dil = P.dil;
+        const int h2 = (K - 1) / 2, h1 = h2 * dil;
+        const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+        float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
+        const int nchunk = 2 * K;
+        // chunk g of the pair's weight stream (conv1's taps, then conv2's) -> ring slot g & 3; a wave moves 2 of its 8 fragments
+        // (the stream's base pointers pinned in scalar registers: re-reading them from the kernel arguments at every request
+        // would put an lgkmcnt(0) wait — which also waits for the LDS reads in flight — into every tap)
+        const uint64_t w1a = (uint64_t)P.w1rx + wave * 2048, w2a = (uint64_t)P.w2rx + wave * 2048 - (uint64_t)K * CHUNK;
+        const uint32_t w1lo = __builtin_amdgcn_readfirstlane((uint32_t)w1a), w1hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1a >> 32));
+        const uint32_t w2lo = __builtin_amdgcn_readfirstlane((uint32_t)w2a), w2hi = __builtin_amdgcn_readfirstlane((uint32_t)(w2a >> 32));
+        auto issue = [&](int g) {
+            const uint64_t base = g < K ? ((uint64_t)w1hi << 32 | w1lo) : ((uint64_t)w2hi << 32 | w2lo);
+            const char *src = (const char *)base + (size_t)g * CHUNK + lane * 16;
+            char *dst = ring + (g & 3) * CHUNK + wave * 2048;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+        };
+        if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the tile and the ring
+        issue(0);
+        issue(1);
+        issue(2);
+
+        // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        // (two workgroups per CU whatever the register count — LDS decides — so every staging load of the tile is in flight at once)
+        stage_act_buf<20, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
+        // the residual operand (the tile's centre rows again, in the accumulator layout) is requested right behind the
+        // staging loads, while their lines are still in L2, and waits in registers until the epilogue
+        const int nrows = (L - t0 < TM) ? (L - t0) : TM;
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+        // conv2's accumulator layout: [mt][nt][wt][lt][i] = time row mt*32 + 8g + 2i + lt, channel nt*32 + 2c + wt — 8 bytes per lane
+        const int voff0 = ((wave * 32 * MT + 8 * lg) * CP + 2 * lc) * 4;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 resv[MT][NT][2][4];
+        auto load_res = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            resv[mt][nt][lt][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff0 + nt * 128, (mt * 32 + 2 * i + lt) * CP * 4, 0);
+        };
+        if constexpr (!MERGE) load_res();      // (the merged form holds the branches' running sum: it loads in the epilogue)
+        ZV_STAMP(1)
+        __syncthreads();                                // X complete; the barrier drains the first three chunks too
+        ZV_STAMP(2)
+
+        floatx4 acc[MT][NT][2][2];
+        half8 a[2][MT][2], b[2][NT][2];
+        int g = 0;                                      // chunk = tap of the stream
+        // one step = 32 channels: the operand's two 16-row tiles per 32-row block (rows 2c + lt), the weights' two 16-channel tiles per
+        // output tile, both from LDS; a chunk = [step 2][nt 2][wt 2] fragments
+#define ZV_LDR(slot, aptr, boff)                                                                                      \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                             \
+            _Pragma("unroll") for (int lt = 0; lt < 2; lt++) a[slot][mt][lt] = *(const half8 *)(ap_ + (mt * 32 + lt) * RS);    \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                             \
+            _Pragma("unroll") for (int wt = 0; wt < 2; wt++) b[slot][nt][wt] = *(const half8 *)(bp_ + (boff) + (nt * 2 + wt) * 1024); \
+    }
+#define ZV_MF(slot, SW, Z)                                \
+    mfma16_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);    \
+    __builtin_amdgcn_sched_barrier(0);
+        // one tap: step 0 | wait for the next chunk, barrier, request the chunk three ahead | step 1 (which already reads the
+        // next tap's first fragments)
+#define ZV_TAP(SW, Z0, tapstride)                                                                         \
+    {                                                                                                     \
+        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
+        ZV_LDR(1, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
+        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if (g + 3 < nchunk) issue(g + 3);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ap += (tapstride);                                                                                \
+        bp_ = bn_;                                                                                        \
+        ZV_LDR(0, ap, 0) ZV_MF(1, SW, false)                                                              \
+        g++;                                                                                              \
+    }
+        // ---- conv1 (dilated), transposed product
+        {
+            const char *ap = abase;
+            {
+                const char *bp_ = bl;
+                ZV_LDR(0, ap, 0)
+            }
+            ZV_TAP(true, true, dil * RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
+        }
+        ZV_STAMP(3)
+        // every wave is done reading X: its LDS region becomes XT (raw barriers here: __syncthreads would drain the weight
+        // stream, whose next chunks are in flight under the pack)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        ZV_STAMP(4)
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i.  acc[mt][nt][wt][lt][i]: time row
+        // mt*32 + 2c + lt, channel nt*32 + 16 wt + 4g + i
+        {
+            const float sl = P.slope;
+            const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                float4 bq[2];
+#pragma unroll
+                for (int wt = 0; wt < 2; wt++) bq[wt] = *(const float4 *)(P.b1 + nt * 32 + 16 * wt + 4 * lg);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+                    {
+                        const int i = wave * 32 * MT + mt * 32 + 2 * lc + lt;
+                        const int t = t0 - h2 + i;
+                        const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                        for (int wt = 0; wt < 2; wt++)
+                        {
+                            uint2 pk = lrelu4_f16(acc[mt][nt][wt][lt][0] + bq[wt].x, acc[mt][nt][wt][lt][1] + bq[wt].y,
+                                                  acc[mt][nt][wt][lt][2] + bq[wt].z, acc[mt][nt][wt][lt][3] + bq[wt].w, sl);
+                            if (edge)
+                            {
+                                pk.x = in ? pk.x : 0u;
+                                pk.y = in ? pk.y : 0u;
+                            }
+                            *(uint2 *)(smem + i * RS + (nt * 32 + 16 * wt + 4 * lg) * 2) = pk;
+                        }
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        ZV_STAMP(5)
+        // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
+        {
+            const char *ap = abase;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+            }
+            ZV_TAP(false, true, RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
+        }
+#undef ZV_TAP
+#undef ZV_MF
+#undef ZV_LDR
+
+        // ---- epilogue: out = y + (conv2 + b2); descriptors over exactly this tile's valid rows (see resblock_pair_kernel)
+        ZV_STAMP(6)
+        if constexpr (MERGE) load_res();
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+        {
+            const float2 bias = *(const float2 *)(P.b2 + nt * 32 + 2 * lc);
+            const int voff = voff0 + nt * 128;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        float v0 = (acc[mt][nt][0][lt][i] + bias.x) + __uint_as_float(resv[mt][nt][lt][i][0]);
+                        float v1 = (acc[mt][nt][1][lt][i] + bias.y) + __uint_as_float(resv[mt][nt][lt][i][1]);
+                        if constexpr (MERGE)
+                        {
+                            msum[mt][nt][0][lt][i] = jb == 0 ? v0 : msum[mt][nt][0][lt][i] + v0;
+                            msum[mt][nt][1][lt][i] = jb == 0 ? v1 : msum[mt][nt][1][lt][i] + v1;
+                            if (jb != jobs.njobs - 1) continue;
+                            v0 = msum[mt][nt][0][lt][i];
+                            v1 = msum[mt][nt][1][lt][i];
+                        }
+                        const u32x2 o = {__float_as_uint(v0), __float_as_uint(v1)};
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, (mt * 32 + 2 * i + lt) * CP * 4, ZV_ST_AUX);
+                    }
+        }
+#ifdef ZV_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ZV_STAMP(7)
+    }
+}
+
 template <bool MERGE>
 static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int Lmax, int Kmax, int dmax)
 {
@@ -2089,11 +2337,15 @@ static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int
     js.ring_off = round_up((BM + Kmax * dmax) * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
     if (lds > 80 * 1024) return hipErrorInvalidValue;
-    auto kern = resblock_pair64_kernel<MERGE>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
-    return hipGetLastError();
+    bool x16 = knob(ZV_PAIR16) != 0;          // the 16 x 16 x 32 form wherever its weight stream exists (same bits)
+    for (int i = 0; i < njobs; i++) x16 = x16 && js.j[i].w1rx && js.j[i].w2rx;
+    auto launch = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+        return hipGetLastError();
+    };
+    return x16 ? launch(resblock_pair64x_kernel<MERGE>) : launch(resblock_pair64_kernel<MERGE>);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2328,6 +2580,250 @@ __global__ __launch_bounds__(256, 2) void resblock_block64_kernel(const TripleJo
             }
 }
 
+__global__ __launch_bounds__(256, 2) void resblock_block64x_kernel(const TripleJobs jobs)
+{
+    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
+    constexpr int CHUNK = 8 * 1024;
+    const TripleJob &P = jobs.j[blockIdx.z];
+    const int K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int sumd = 0, dmax = 1;
+    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
+    const int H = h2 * (sumd + nd);
+    const int TM = BM - 2 * H;
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
+    const int XM = h2 * dmax;                         // zero margin of the operand region on either side of the tile
+    const int xrows = BM + 2 * XM + 2 * dmax;         // + slack: the last tap's look-ahead reads one tap past the end
+    const bool edge = t0 - H < 0 || t0 - H + BM > L;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char *ring = smem + jobs.ring_off;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lg = lane >> 4;
+    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair16_kernel)
+    const char *bl = ring + lane * 16;
+    const int nchunk = 2 * K * nd;                    // the block's weight stream: per pair conv1's taps, then conv2's
+    // chunk g -> ring slot g & 3; base pointers of the (at most six) convs in scalar registers
+    uint32_t wlo[2 * TRIPLE_MAX_DIL], whi[2 * TRIPLE_MAX_DIL];
+#pragma unroll
+    for (int c = 0; c < 2 * TRIPLE_MAX_DIL; c++)
+    {
+        const int d = c >> 1 < nd ? c >> 1 : 0;
+        const uint64_t a = (uint64_t)((c & 1) ? P.w2[d] : P.w1[d]) + wave * 2048;
+        wlo[c] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        whi[c] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    }
+    auto issue = [&](int g) {
+        const int c = g / K, tap = g - c * K;         // conv index (2 * pair + conv), tap
+        uint32_t lo = wlo[0], hi = whi[0];
+#pragma unroll
+        for (int q = 1; q < 2 * TRIPLE_MAX_DIL; q++)
+            if (c == q) { lo = wlo[q]; hi = whi[q]; }
+        const char *src = (const char *)((uint64_t)hi << 32 | lo) + (size_t)tap * CHUNK + lane * 16;
+        char *dst = ring + (g & 3) * CHUNK + wave * 2048;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+    // the whole operand region starts as zeros (margins stay zero for the whole kernel; nothing in it is ever uninitialised)
+    for (int i = tid; i < xrows * RS / 16; i += 256) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+    // tile row i <-> time t0 - H + i; register [mt][nt][wt][lt][i] (conv2's accumulator layout): row wave*64 + mt*32 + 8g + 2i + lt,
+    // channel nt*32 + 2c + wt — the lane's two weight tiles are neighbouring channels: 8-byte loads / stores, 4-byte operand writes
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    float yreg[MT][NT][2][2][4];
+    {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        const int voff = ((t0 - H + wave * 32 * MT + 8 * lg) * CP + 2 * lc) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_y, voff + nt * 128 + (mt * 32 + 2 * i + lt) * CP * 4, 0, 0);
+                        yreg[mt][nt][0][lt][i] = __uint_as_float(v[0]);
+                        yreg[mt][nt][1][lt][i] = __uint_as_float(v[1]);
+                    }
+    }
+    __syncthreads();                                  // zeros written (and the first chunks landed)
+    const float sl = P.slope;
+    int g = 0;
+    floatx4 acc[MT][NT][2][2];
+    half8 a[2][MT][2], b[2][NT][2];
+#define ZV_LDR(slot, aptr, boff)                                                                                      \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                             \
+            _Pragma("unroll") for (int lt = 0; lt < 2; lt++) a[slot][mt][lt] = *(const half8 *)(ap_ + (mt * 32 + lt) * RS);    \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                             \
+            _Pragma("unroll") for (int wt = 0; wt < 2; wt++) b[slot][nt][wt] = *(const half8 *)(bp_ + (boff) + (nt * 2 + wt) * 1024); \
+    }
+#define ZV_MF(slot, SW, Z)                                \
+    mfma16_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);    \
+    __builtin_amdgcn_sched_barrier(0);
+#define ZV_TAP(SW, Z0, tapstride)                                                                         \
+    {                                                                                                     \
+        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
+        ZV_LDR(1, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
+        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if (g + 3 < nchunk) issue(g + 3);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ap += (tapstride);                                                                                \
+        bp_ = bn_;                                                                                        \
+        ZV_LDR(0, ap, 0) ZV_MF(1, SW, false)                                                              \
+        g++;                                                                                              \
+    }
+    for (int d = 0; d < nd; d++)
+    {
+        const int dil = P.dil[d], h1 = h2 * dil;
+        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + BM - 1 (Y is zero outside [0, L): so is X)
+        {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                        {
+                            const int row = wave * 32 * MT + mt * 32 + 8 * lg + 2 * i + lt;
+                            half2v h;
+                            h[0] = (_Float16)lrelu_max(yreg[mt][nt][0][lt][i], sl);
+                            h[1] = (_Float16)lrelu_max(yreg[mt][nt][1][lt][i], sl);
+                            *(half2v *)(smem + (XM + row) * RS + (nt * 32 + 2 * lc) * 2) = h;
+                        }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // (raw: the weight stream stays in flight)
+        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap * dil
+        {
+            const char *ap = abase + (XM - h1) * RS;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+            }
+            ZV_TAP(true, true, dil * RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading X: its rows become XT
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L): acc[mt][nt][wt][lt][i] = time row mt*32 + 2c + lt, channel nt*32 + 16 wt + 4g + i
+        {
+            const float *b1 = P.b1[d];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                float4 bq[2];
+#pragma unroll
+                for (int wt = 0; wt < 2; wt++) bq[wt] = *(const float4 *)(b1 + nt * 32 + 16 * wt + 4 * lg);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+                    {
+                        const int i = wave * 32 * MT + mt * 32 + 2 * lc + lt;
+                        const int t = t0 - H + i;
+                        const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                        for (int wt = 0; wt < 2; wt++)
+                        {
+                            uint2 pk = lrelu4_f16(acc[mt][nt][wt][lt][0] + bq[wt].x, acc[mt][nt][wt][lt][1] + bq[wt].y,
+                                                  acc[mt][nt][wt][lt][2] + bq[wt].z, acc[mt][nt][wt][lt][3] + bq[wt].w, sl);
+                            if (edge)
+                            {
+                                pk.x = in ? pk.x : 0u;
+                                pk.y = in ? pk.y : 0u;
+                            }
+                            *(uint2 *)(smem + (XM + i) * RS + (nt * 32 + 16 * wt + 4 * lg) * 2) = pk;
+                        }
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
+        {
+            const char *ap = abase + (XM - h2) * RS;
+            {
+                const char *bp_ = bl + (g & 3) * CHUNK;
+                ZV_LDR(0, ap, 0)
+            }
+            ZV_TAP(false, true, RS)
+            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
+        }
+        {
+            const float *b2 = P.b2[d];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+            {
+                const float2 bias = *(const float2 *)(b2 + nt * 32 + 2 * lc);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                        {
+                            const float v0 = (acc[mt][nt][0][lt][i] + bias.x) + yreg[mt][nt][0][lt][i];
+                            const float v1 = (acc[mt][nt][1][lt][i] + bias.y) + yreg[mt][nt][1][lt][i];
+                            bool in = true;
+                            if (edge)
+                            {
+                                const int t = t0 - H + wave * 32 * MT + mt * 32 + 8 * lg + 2 * i + lt;
+                                in = t >= 0 && t < L;
+                            }
+                            yreg[mt][nt][0][lt][i] = in ? v0 : 0.f;
+                            yreg[mt][nt][1][lt][i] = in ? v1 : 0.f;
+                        }
+            }
+        }
+        if (d + 1 < nd)
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave is done reading XT before the next X goes over it
+        }
+    }
+#undef ZV_TAP
+#undef ZV_MF
+#undef ZV_LDR
+    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int row = wave * 32 * MT + mt * 32 + 8 * lg + 2 * i + lt;
+                    const int t = t0 - H + row;
+                    const int voff = (row >= H && row < H + TM && t >= 0) ? (t * CP + nt * 32 + 2 * lc) * 4 : -8;
+                    const u32x2 o = {__float_as_uint(yreg[mt][nt][0][lt][i]), __float_as_uint(yreg[mt][nt][1][lt][i])};
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, ZV_ST_AUX);
+                }
+}
+
 // the blocks resblock_block64_kernel takes: 64 channels, few taps (the halo of n_dil pairs leaves most of the 256-row tile)
 bool block64_supported(int Cp, int K, const int *dil, int n_dil)
 {
@@ -2363,6 +2859,22 @@ hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const
     js.ring_off = round_up(rows_max * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
     if (lds > 80 * 1024) return hipErrorInvalidValue;
+    bool x16 = knob(ZV_PAIR16) != 0;          // the 16 x 16 x 32 form wherever its weight stream exists (same bits)
+    for (int i = 0; i < njobs; i++)
+        for (int d = 0; d < jobs[i].n_dil; d++) x16 = x16 && jobs[i].w1x[d] && jobs[i].w2x[d];
+    if (x16)
+    {
+        for (int i = 0; i < PAIR_MAX_JOBS; i++)
+            for (int d = 0; d < TRIPLE_MAX_DIL; d++)
+            {
+                js.j[i].w1[d] = js.j[i].w1x[d];
+                js.j[i].w2[d] = js.j[i].w2x[d];
+            }
+        hipError_t e = hipFuncSetAttribute((const void *)resblock_block64x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(resblock_block64x_kernel, dim3(round_up(gx, 8), 1, njobs), dim3(256), lds, s, js);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute((const void *)resblock_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(resblock_block64_kernel, dim3(round_up(gx, 8), 1, njobs), dim3(256), lds, s, js);

@@ -163,6 +163,7 @@ struct PairJob
     float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
     const void  *w1, *w2;    // packed by pack_pair_weight (zero-padded per-tile segments)
     const void  *w1r, *w2r;  // packed by pack_pair_weight_ring ([tap][kc][ntile] fragments), or null
+    const void  *w1rx, *w2rx; // packed by pack_pair_weight_ring16 for resblock_pair64x_kernel, or null
     const void  *w1x, *w2x;  // packed by pack_pair_weight16 (conv1: A-operand form, conv2: B-operand form) for resblock_pair16_kernel, or null
     const float *b1, *b2;
     int          L, Cp, K, dil;
@@ -197,6 +198,7 @@ void       pack_pair_weight16(const uint16_t *w, int K, int C, int Cp, uint16_t 
 // the same weight as the stream resblock_pair64_kernel moves through its LDS ring: [tap][kc][ntile][lane][8 halfs]
 size_t     pair_ring_weight_halfs(int Cp, int K);
 void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
+void       pack_pair_weight_ring16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout);
 // merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
 // stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);
@@ -210,6 +212,7 @@ struct TripleJob
     const float *y;                       // [L][Cp] f32 block input (may be shared by several jobs)
     float       *out;                     // [L][Cp] f32 block output, must not alias y
     const void  *w1[TRIPLE_MAX_DIL], *w2[TRIPLE_MAX_DIL];    // pack_pair_weight layout
+    const void  *w1x[TRIPLE_MAX_DIL], *w2x[TRIPLE_MAX_DIL];  // launch_block64: the ring stream in 16 x 16 x 32 fragment order (pack_pair_weight_ring16), or null
     const float *b1[TRIPLE_MAX_DIL], *b2[TRIPLE_MAX_DIL];
     int          dil[TRIPLE_MAX_DIL];
     int          n_dil;

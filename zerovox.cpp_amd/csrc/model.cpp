@@ -282,6 +282,10 @@ Model::Model(const std::string &path, int dev) : device(dev)
                             void **rd = q ? &rp.r2 : &rp.r1;
                             *rd = dev_alloc(rk.size() * 2);
                             ZV_HIP(hipMemcpy(*rd, rk.data(), rk.size() * 2, hipMemcpyHostToDevice));
+                            pack_pair_weight_ring16((const uint16_t *)g.get(nm).data, rp.c1.K, C, 64, rk.data(), q == 1);
+                            void **rxd = q ? &rp.rx2 : &rp.rx1;
+                            *rxd = dev_alloc(rk.size() * 2);
+                            ZV_HIP(hipMemcpy(*rxd, rk.data(), rk.size() * 2, hipMemcpyHostToDevice));
                         }
                     }
                 }
@@ -1045,6 +1049,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                     {
                         t.w1[d] = rp[d].r1;
                         t.w2[d] = rp[d].r2;
+                        t.w1x[d] = rp[d].rx1;
+                        t.w2x[d] = rp[d].rx2;
                         t.b1[d] = rp[d].c1.bias;
                         t.b2[d] = rp[d].c2.bias;
                         t.dil[d] = voc_.dil[d];
@@ -1100,6 +1106,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 p.w2r = rp.r2;
                 p.w1x = rp.x1;
                 p.w2x = rp.x2;
+                p.w1rx = rp.rx1;
+                p.w2rx = rp.rx2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
                 p.Cp = Cp;

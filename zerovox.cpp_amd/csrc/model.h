@@ -195,7 +195,7 @@ class Model
     ConvW  load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin = -1, bool gemm_pack = false);
     ConvW  load_upsample(const GgufFile &g, int idx, int stride, int expect_cin);
 
-    struct ResPair { ConvW c1, c2; void *p1 = nullptr, *p2 = nullptr, *r1 = nullptr, *r2 = nullptr, *x1 = nullptr, *x2 = nullptr; };   // p1/p2: fused-kernel weight layout, r1/r2: LDS-ring layout (64 channels)
+    struct ResPair { ConvW c1, c2; void *p1 = nullptr, *p2 = nullptr, *r1 = nullptr, *r2 = nullptr, *x1 = nullptr, *x2 = nullptr, *rx1 = nullptr, *rx2 = nullptr; };   // p1/p2: fused-kernel weight layout, r1/r2: LDS-ring layout (64 channels)
     struct Voc
     {
         float *mean = nullptr, *scale = nullptr;
