@@ -3468,6 +3468,284 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #endif
 }
 
+// ---- the whole-block kernel on v_mfma_f32_16x16x32_f16 (round 4; layouts as in resblock_pair16_kernel, same bits) ----
+// one conv of the 32-channel block: one step per tap (32 channels), operand rows (two 16-row tiles per 32-row block: rows 2c + lt)
+// and weight fragments (two 16-channel tiles) from LDS, one tap ahead of the MFMAs that consume them
+template <int MT, bool SWAP>
+__device__ __forceinline__ void mfma32x_ldsw(floatx4 (&acc)[MT][1][2][2], const char *ap, int dilRS, const char *wl, int K)
+{
+    constexpr int RS = 32 * 2 + 16;
+    half8 a[2][MT][2], b[2][1][2];
+#define ZV_LD(slot, aptr, woff)                                                                                       \
+    {                                                                                                                 \
+        const char *ap_ = (aptr);                                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                             \
+            _Pragma("unroll") for (int lt = 0; lt < 2; lt++) a[slot][mt][lt] = *(const half8 *)(ap_ + (mt * 32 + lt) * RS);    \
+        _Pragma("unroll") for (int wt = 0; wt < 2; wt++) b[slot][0][wt] = *(const half8 *)(wl + (woff) + wt * 1024);   \
+    }
+#define ZV_ST(slot, Z)                                     \
+    mfma16_step<MT, 1, SWAP, Z>(acc, a[slot], b[slot]);    \
+    __builtin_amdgcn_sched_barrier(0);
+    // tap 0 starts the accumulators from the constant 0; the other K - 1 taps (K odd) go two at a time.  The last iteration's
+    // look-ahead reads one tap past the end (operand rows and weight-buffer slack that exist) and is never used.
+    const char *t1 = ap + dilRS;
+    ZV_LD(0, ap, 0)
+    ZV_LD(1, t1, 2 * 1024) ZV_ST(0, true)
+    for (int it = (K - 1) >> 1; it > 0; it--)
+    {
+        const char *t2 = t1 + dilRS, *t3 = t2 + dilRS;
+        ZV_LD(0, t2, 4 * 1024) ZV_ST(1, false)
+        ZV_LD(1, t3, 6 * 1024) ZV_ST(0, false)
+        t1 = t3;
+        wl += 4 * 1024;
+    }
+#undef ZV_ST
+#undef ZV_LD
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_st_b32(unsigned addr, unsigned v)
+{
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// the operand writes (two neighbouring channels per lane and row: 4-byte stores) and the xt pack, unrolled at compile time
+template <int MT_, int I = 0>
+__device__ __forceinline__ void xwrite_all16(unsigned xa, const float (&y)[MT_][2][2][4], float sl)
+{
+    constexpr int mt = I / 8, lt = (I / 4) % 2, i = I % 4;
+    half2v h;
+    h[0] = (_Float16)lrelu_max(y[mt][0][lt][i], sl);
+    h[1] = (_Float16)lrelu_max(y[mt][1][lt][i], sl);
+    lds_st_b32<(mt * 32 + 2 * i + lt) * 80>(xa, *(const unsigned *)&h);
+    if constexpr (I + 1 < MT_ * 8) xwrite_all16<MT_, I + 1>(xa, y, sl);
+}
+template <int MT_, int I = 0>
+__device__ __forceinline__ void pack_all16(unsigned pa, const uint2 (&pk)[MT_][2][2])
+{
+    constexpr int mt = I / 4, lt = (I / 2) % 2, wt = I % 2;
+    lds_st_b64<(mt * 32 + lt) * 80 + 32 * wt>(pa, pk[mt][lt][wt]);
+    if constexpr (I + 1 < MT_ * 4) pack_all16<MT_, I + 1>(pa, pk);
+}
+
+template <int MT, int R>
+__global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32x_kernel(const TripleJobs jobs)
+{
+    constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
+    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
+    // workgroup -> (job, tile): with `il` jobs interleaved the MRF branches of one stretch of the sequence run next to each
+    // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM.
+    const int il = jobs.interleave;
+    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
+    const int jb = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
+    const TripleJob &P = jobs.j[jb];
+    int H;
+    {
+        int sumd0 = 0;
+        for (int d = 0; d < P.n_dil; d++) sumd0 += P.dil[d];
+        H = ((P.K - 1) / 2) * (sumd0 + P.n_dil);
+    }
+    const int TM = R - 2 * H;
+    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
+    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
+    if (vt >= tps * jobs.segs.nseg) return;
+    const int useg = vt / tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int t0 = (vt - useg * tps) * TM;
+    if (t0 >= L) return;
+    const bool edge = t0 - H < 0 || t0 - H + R > L;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 16 x 16 x 32 layouts (see resblock_pair16_kernel): lane (c, g); the f32 tile in conv2's accumulator layout
+    // y[mt][wt][lt][i] = tile row wave*32*MT + mt*32 + 8g + 2i + lt, channel 2c + wt
+    const int lc = lane & 15, lg = lane >> 4;
+    const int irow0 = wave * 32 * MT + 8 * lg;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#ifdef ZV_STAMPS
+    const int stamp_wg = blockIdx.x;
+    int stamp_k = 1;
+#endif
+    ZV_STAMP(0)
+
+    const int K = P.K, nd = P.n_dil;
+    const int h2 = (K - 1) / 2;
+    int dmax = 1;
+    for (int d = 0; d < nd; d++) dmax = P.dil[d] > dmax ? P.dil[d] : dmax;
+    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
+    const int XM = h2 * dmax;
+    const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
+    const int nb = ((K * NKC + 3) >> 2) >> 1;         // 8-step bodies per conv
+    const int nblk = 8 * nb;                          // weight fragments per conv (real ones first, zero blocks behind)
+
+    // Two weight buffers where they fit (jobs.db_mask: 3- and 7-tap branches): a conv's fragments are requested while the
+    // conv BEFORE it runs and have a whole MFMA loop plus a pack / epilogue phase to land.  With one buffer (11 taps) the
+    // request can only follow the barrier that ends the previous conv and the next barrier waits for it: phase stamps of
+    // that form show 2 us of DMA latency in each of a block's six pack / epilogue phases (27.6 us per workgroup).
+    // The biases of the block's six convs sit in LDS, so nothing in the loop below waits on the vector-memory counter but
+    // the barriers that are meant to.
+    const bool db = (jobs.db_mask >> jb) & 1;
+    char *wlds = smem + round_up(xrows * RS, 1024);
+    char *wlds2 = db ? wlds + nblk * 1024 : wlds;                  // conv2's weights
+    float *blds = (float *)(wlds + (db ? 2 : 1) * nblk * 1024 + 2048);      // behind the last-prefetch slack: [d][conv][32]
+    dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
+    if (tid < 64 * nd)
+    {
+        const int d_ = tid >> 6, c_ = tid & 31;
+        blds[tid] = (tid & 32) ? P.b2[d_][c_] : P.b1[d_][c_];
+    }
+    // the margins of the operand region stay zero for the whole kernel: rows [0, XM) and [XM + R, xrows)
+    {
+        const int lo = XM * RS / 16, hi0 = (XM + R) * RS / 16, hi = xrows * RS / 16;
+        for (int i = tid; i < lo; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = hi0 + tid; i < hi; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+    }
+    // tile row i <-> time t0 - H + i; rows outside [0, L) are out of the descriptor's range and read as 0
+    float yreg[MT][2][2][4];
+    {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
+        const int voff = ((t0 - H + irow0) * CP + 2 * lc) * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_y, voff + (mt * 32 + 2 * i + lt) * CP * 4, 0, 0);
+                    yreg[mt][0][lt][i] = __uint_as_float(v[0]);
+                    yreg[mt][1][lt][i] = __uint_as_float(v[1]);
+                }
+    }
+
+    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;
+    const char *wl = wlds + lane * 16, *wl2 = wlds2 + lane * 16;
+    const float sl = P.slope;
+    for (int d = 0; d < nd; d++)
+    {
+        const int dil = P.dil[d], h1 = h2 * dil;
+        if (d)
+        {
+            // the previous conv2 is done reading XT and its weights (raw barrier: conv1's weights may be in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!db) dma_weights32(P.w1[d], wlds, nblk, wave, lane, NWV);
+        }
+        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
+        {
+            static_assert(RS == 80, "xwrite_all / pack_all carry the row stride");
+            xwrite_all16<MT>((unsigned)(uintptr_t)(smem + (XM + irow0) * RS + 2 * lc * 2), yreg, sl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                       // X complete, conv1's weights landed (the barrier drains the DMA)
+        if (db) dma_weights32(P.w2[d], wlds2, nblk, wave, lane, NWV);      // under conv1 and the pack
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
+
+        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
+        floatx4 acc[MT][1][2][2];
+        mfma32x_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, K);
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
+        // every wave is done reading X and conv1's weights (raw barrier: conv2's weights may be in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // (the biases are read before any request goes out: hipcc orders an LDS read behind a pending LDS-DMA with vmcnt(0))
+        // (raw ds_reads: hipcc would order a visible LDS read behind the weight DMA in flight with vmcnt(0) and drain it here)
+        float4 bq[2];
+        float2v bias2;
+        {
+            // conv1: channels 16 wt + 4g + i; conv2: channels 2c + wt
+            const unsigned ba = (unsigned)(uintptr_t)(blds + d * 64 + 4 * lg), bb = (unsigned)(uintptr_t)(blds + d * 64 + 32 + 2 * lc);
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b64 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bias2)
+                         : "v"(ba), "v"(bb)
+                         : "memory");
+        }
+        if (!db) dma_weights32(P.w2[d], wlds, nblk, wave, lane, NWV);
+        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L): acc[mt][0][wt][lt][i] = tile row mt*32 + 2c + lt, channel 16 wt + 4g + i
+        {
+            const unsigned pa = (unsigned)(uintptr_t)(smem + (XM + wave * 32 * MT + 2 * lc) * RS + 4 * lg * 2);
+            uint2 pkv[MT][2][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+                {
+                    const int i = wave * 32 * MT + mt * 32 + 2 * lc + lt;
+                    const int t = t0 - H + i;
+                    const bool in = !edge || (t >= 0 && t < L);
+#pragma unroll
+                    for (int wt = 0; wt < 2; wt++)
+                    {
+                        uint2 pk = lrelu4_f16(acc[mt][0][wt][lt][0] + bq[wt].x, acc[mt][0][wt][lt][1] + bq[wt].y,
+                                              acc[mt][0][wt][lt][2] + bq[wt].z, acc[mt][0][wt][lt][3] + bq[wt].w, sl);
+                        if (edge)
+                        {
+                            pk.x = in ? pk.x : 0u;
+                            pk.y = in ? pk.y : 0u;
+                        }
+                        pkv[mt][lt][wt] = pk;
+                    }
+                }
+            pack_all16<MT>(pa, pkv);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                       // XT complete, conv2's weights landed
+        if (db && d + 1 < nd) dma_weights32(P.w1[d + 1], wlds, nblk, wave, lane, NWV);      // under conv2, the update and the next X write
+#ifdef ZV_STAMPS
+        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
+#endif
+
+        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
+        mfma32x_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
+        {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const float v0 = (acc[mt][0][0][lt][i] + bias2[0]) + yreg[mt][0][lt][i];
+                        const float v1 = (acc[mt][0][1][lt][i] + bias2[1]) + yreg[mt][1][lt][i];
+                        bool in = true;
+                        if (edge)
+                        {
+                            const int t = t0 - H + irow0 + mt * 32 + 2 * i + lt;
+                            in = t >= 0 && t < L;
+                        }
+                        yreg[mt][0][lt][i] = in ? v0 : 0.f;
+                        yreg[mt][1][lt][i] = in ? v1 : 0.f;
+                    }
+        }
+    }
+
+    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
+    float *const out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int row = irow0 + mt * 32 + 2 * i + lt;
+                const int t = t0 - H + row;
+                const int voff = (row >= H && row < H + TM && t >= 0) ? (t * CP + 2 * lc) * 4 : -8;
+                const u32x2 o = {__float_as_uint(yreg[mt][0][lt][i]), __float_as_uint(yreg[mt][1][lt][i])};
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, ZV_ST_AUX);
+            }
+#ifdef ZV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZV_STAMP(11)
+#endif
+}
+
 bool triple_supported(int Cp, int K, const int *dil, int n_dil)
 {
     if (Cp != 32 || n_dil < 1 || n_dil > TRIPLE_MAX_DIL || !pair_supported(Cp, K) || (K & 1) == 0) return false;
@@ -3547,6 +3825,20 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
                 hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
+            // the 16 x 16 x 32 form wherever its weight copies exist (ZV_PAIR16 = 0: the 32 x 32 x 16 form; same bits)
+            bool x16 = knob(ZV_PAIR16) != 0;
+            for (int i = 0; i < njobs; i++)
+                for (int d = 0; d < jobs[i].n_dil; d++) x16 = x16 && jobs[i].w1x[d] && jobs[i].w2x[d];
+            if (x16)
+            {
+                for (int i = 0; i < PAIR_MAX_JOBS; i++)
+                    for (int d = 0; d < TRIPLE_MAX_DIL; d++)
+                    {
+                        js.j[i].w1[d] = js.j[i].w1x[d];
+                        js.j[i].w2[d] = js.j[i].w2x[d];
+                    }
+                return R == 512 ? launch(resblock_block32x_kernel<2, 512>, 512) : launch(resblock_block32x_kernel<2, 256>, 256);
+            }
             return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
         }
     }

@@ -212,7 +212,9 @@ struct TripleJob
     const float *y;                       // [L][Cp] f32 block input (may be shared by several jobs)
     float       *out;                     // [L][Cp] f32 block output, must not alias y
     const void  *w1[TRIPLE_MAX_DIL], *w2[TRIPLE_MAX_DIL];    // pack_pair_weight layout
-    const void  *w1x[TRIPLE_MAX_DIL], *w2x[TRIPLE_MAX_DIL];  // launch_block64: the ring stream in 16 x 16 x 32 fragment order (pack_pair_weight_ring16), or null
+    // the same weights in 16 x 16 x 32 fragment order, or null: launch_block64 — the ring stream (pack_pair_weight_ring16);
+    // launch_triple — pack_pair_weight16 (conv1 A-operand form, conv2 B-operand form)
+    const void  *w1x[TRIPLE_MAX_DIL], *w2x[TRIPLE_MAX_DIL];
     const float *b1[TRIPLE_MAX_DIL], *b2[TRIPLE_MAX_DIL];
     int          dil[TRIPLE_MAX_DIL];
     int          n_dil;

@@ -1012,6 +1012,8 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                     t.K = rp.c1.K;
                     t.w1[d] = rp.p1;
                     t.w2[d] = rp.p2;
+                    t.w1x[d] = rp.x1;
+                    t.w2x[d] = rp.x2;
                     t.b1[d] = rp.c1.bias;
                     t.b2[d] = rp.c2.bias;
                     t.dil[d] = voc_.dil[d];
