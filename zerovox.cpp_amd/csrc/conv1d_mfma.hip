@@ -4241,6 +4241,366 @@ __device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g
 }
 
 
+// ---- conv_gemm_kernel on v_mfma_f32_16x16x32_f16 (round 4): one half unit = ONE step of 32 channels (same chain per output
+// element as the two k16 steps above: scripts/mfma_shape_bits.hip), 8 x 4 tiles of 16 x 16 per wave.
+//   * operand image: row r's four 16-byte pieces at slots piece ^ ((r >> 1) & 3) — the swizzle under which the 16 x 16 x 32 A
+//     fragment reads (lane = row c of a 16-row tile, k group g = piece) fall on 16 distinct slots per lane group;
+//   * weights (pack_conv_weight_gemm16): per half unit [tile32][wt][lane][8 halfs], column c of tile wt = channel 2c + wt: a lane's
+//     two tiles of a 32-channel group are NEIGHBOURING channels, the epilogue moves 8 bytes per lane (four rows x 128 bytes per
+//     instruction: half the instructions of the 4-byte form);
+//   * the InstanceNorm partial sums keep tile_stats_store's summation order (rows 0-3, 8-11, 16-19, 24-27 then the other half,
+//     each a sequential f64 chain): the chain is handed from lane group to lane group.
+void pack_conv_weight_gemm16(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst)
+{
+    const int ng = conv_gemm_groups(Cout_p), nu = conv_gemm_units(Cin_p, K), ntk = conv_gemm_tiles(Cout_p);
+    size_t gbase = 0;                                // halfs before group g
+    for (int g = 0; g < ng; g++)
+    {
+        const int ntg = (g == ng - 1) ? ntk - 8 * g : 8;          // 8, or 9 in the last group
+        int u = 0;
+        for (int c0 = 0; c0 < Cin_p; c0 += 256)
+        {
+            const int nsub = (std::min(256, Cin_p - c0) + 63) / 64;
+            for (int tap = 0; tap < K; tap++)
+                for (int sub = 0; sub < nsub; sub++, u++)
+                    for (int hf = 0; hf < 2; hf++)
+                        for (int nt = 0; nt < ntg; nt++)
+                            for (int wt = 0; wt < 2; wt++)
+                            {
+                                uint16_t *d = dst + gbase + ((((size_t)u * 2 + hf) * ntg + nt) * 2 + wt) * 512;
+                                for (int lane = 0; lane < 64; lane++)
+                                    for (int j = 0; j < 8; j++)
+                                    {
+                                        const int oc = (g * 8 + nt) * 32 + 2 * (lane & 15) + wt;
+                                        const int ic = c0 + sub * 64 + hf * 32 + 8 * (lane >> 4) + j;
+                                        d[lane * 8 + j] = (oc < OC && ic < IC) ? w[((size_t)oc * IC + ic) * K + tap] : (uint16_t)0;
+                                    }
+                            }
+        }
+        gbase += (size_t)nu * 4 * ntg * 512;
+    }
+}
+
+template <bool EXTRA>
+__device__ __forceinline__ void conv_gemm16_body(const ConvJobs &jobs, const int g, const int rt)
+{
+    constexpr int BM = 256, UNIT = 32768;            // bytes of an 8-tile unit's weight block
+    constexpr int ntg = EXTRA ? 9 : 8;
+    constexpr int AH = 16384, BH = ntg * 2048;       // bytes of a half unit's operand slice / weight fragments
+    constexpr int SLOT = AH + 18432;                 // one ring slot (room for 9 tiles)
+    const ConvJob &J = jobs.j[0];
+    const int useg = rt / jobs.tps;
+    const Seg sg = seg_at(jobs.segs, useg);
+    const int L = sg.rows * jobs.rate;
+    const int m0 = (rt - useg * jobs.tps) * BM;
+    if (m0 >= L) return;
+    const size_t row0 = (size_t)sg.row0 * jobs.rate;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];     // [4 slots][A 16 KiB | B 16 (18) KiB]
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lc = lane & 15, lg = lane >> 4;
+    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, ldx = J.ldx;
+    const int nunits = conv_gemm_units_dev(Cin_p, K), nhalf = 2 * nunits;
+    constexpr int bunit = ntg * 4096;                // bytes of one unit's weight block
+
+    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (unsigned)((size_t)L * ldx * 2));
+    const u32x4s rs_b = make_rsrc((const char *)J.w8x + (size_t)g * nunits * UNIT, (unsigned)((size_t)nunits * bunit));
+
+    // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
+    // slot); the slot holds the 16-byte piece (slot ^ ((row >> 1) & 3)) of the row's 64 bytes
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+    {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ ((row >> 1) & 3);
+        a_voff[i] = ((m0 - J.pad + row) * ldx + piece * 8) * 2;
+    }
+
+    // half-unit walk: (chunk, tap, 64-channel block of the chunk, half)
+    int uc0 = 0, utap = 0, usub = 0, unsub = (min(256, Cin_p) + 63) >> 6, uh = 0;
+    unsigned i_abase = 0;
+    int i_aoff = 0, i_boff = 0;
+    auto issue_begin = [&](int h) {
+        i_abase = lds0 + (h & 3) * SLOT;
+        i_aoff = (utap * dil * ldx + uc0 + usub * 64 + uh * 32) * 2;
+        i_boff = (h >> 1) * bunit + (h & 1) * BH;
+        if (++uh == 2)
+        {
+            uh = 0;
+            if (++usub == unsub)
+            {
+                usub = 0;
+                if (++utap == K)
+                {
+                    utap = 0;
+                    uc0 += 256;
+                    unsub = (min(256, Cin_p - uc0) + 63) >> 6;
+                }
+            }
+        }
+    };
+    auto issue_pa = [&](int i) { dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff)); };
+    auto issue_pb = [&](int i) { dma_piece(rs_b, i_abase + AH + (wave * 2 + i) * 1024, (unsigned)(i_boff + (wave * 2 + i) * 1024 + lane * 16)); };
+    auto issue_part = [&](int i) {
+        issue_pa(i);
+        issue_pb(i);
+    };
+    auto issue_x = [&]() {
+        if (EXTRA && wave < 2) dma_piece(rs_b, i_abase + AH + (16 + wave) * 1024, (unsigned)(i_boff + (16 + wave) * 1024 + lane * 16));
+    };
+    const bool five = EXTRA && wave < 2;             // this wave requests five pieces per half
+
+    // fragment addresses inside a slot: A tile tm (16 rows): row wm*128 + tm*16 + c, piece g, swizzled; B tile tn: fragment wn*4 + tn
+    const int swz = (lc >> 1) & 3;
+    const int a_rd = (wm * 128 + lc) * 64 + ((lg ^ swz) << 4);
+    const int ax_rd = (wave * 32 + lc) * 64 + ((lg ^ swz) << 4);      // the ninth tile: rows wave * 32 ...
+    const int b_rd = AH + wn * 4096 + lane * 16;
+
+    floatx4 acc[8][4];
+    floatx4 accx[2][2];
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // prologue: halves 0, 1, 2 requested
+#pragma unroll
+    for (int h = 0; h < 3; h++)
+        if (h < nhalf)
+        {
+            issue_begin(h);
+            issue_part(0);
+            issue_part(1);
+            issue_x();
+        }
+    // the half about to be consumed: its weight fragments and the first four row tiles' operand fragments are read at the END of the
+    // previous iteration (that half has landed for every wave one barrier earlier), so that the MFMAs start right behind the barrier
+    half8 aA[4], bb[4], axA, bxb[2];
+#define ZV_G16_READ0(hn)                                                                                          \
+    {                                                                                                             \
+        const char *nb_ = smem + ((hn) & 3) * SLOT;                                                               \
+        _Pragma("unroll") for (int tm = 0; tm < 4; tm++) aA[tm] = *(const half8 *)(nb_ + a_rd + tm * 1024);       \
+        _Pragma("unroll") for (int tn = 0; tn < 4; tn++) bb[tn] = *(const half8 *)(nb_ + b_rd + tn * 1024);       \
+        if constexpr (EXTRA)                                                                                      \
+        {                                                                                                         \
+            axA = *(const half8 *)(nb_ + ax_rd);                                                                  \
+            bxb[0] = *(const half8 *)(nb_ + AH + 16 * 1024 + lane * 16);                                          \
+            bxb[1] = *(const half8 *)(nb_ + AH + 17 * 1024 + lane * 16);                                          \
+        }                                                                                                         \
+    }
+    {
+        if (nhalf > 2)
+        {
+            if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ZV_G16_READ0(0)
+    }
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nhalf; h++)
+    {
+        if (h > 0)
+        {
+            if (h + 2 < nhalf)
+            {
+                if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const bool more = h + 3 < nhalf;
+        if (more) issue_begin(h + 3);
+        const char *buf = smem + (h & 3) * SLOT;
+        // this half's other four row tiles (+ the ninth tile's second row tile), then the MFMAs of the first four
+        half8 aB[4], axB, bcur[4], bxc[2];
+#pragma unroll
+        for (int tm = 0; tm < 4; tm++) aB[tm] = *(const half8 *)(buf + a_rd + (4 + tm) * 1024);
+        if constexpr (EXTRA) axB = *(const half8 *)(buf + ax_rd + 1024);
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) bcur[tn] = bb[tn];
+        if constexpr (EXTRA)
+        {
+            bxc[0] = bxb[0];
+            bxc[1] = bxb[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#define ZV_G16_COL(av, tmb, tn, ZERO)                                                                                   \
+    _Pragma("unroll") for (int tm = 0; tm < 4; tm++)                                                                    \
+        acc[(tmb) + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[tm], bcur[tn], (ZERO) ? zero4 : acc[(tmb) + tm][tn], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+        if (h == 0)
+        {
+            ZV_G16_COL(aA, 0, 0, true)
+            if (more) issue_pa(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aA, 0, 1, true)
+            ZV_G16_COL(aA, 0, 2, true)
+            if (more) issue_pb(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aA, 0, 3, true)
+            if constexpr (EXTRA)
+            {
+                accx[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axA, bxc[0], zero4, 0, 0, 0);
+                accx[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axA, bxc[1], zero4, 0, 0, 0);
+            }
+        }
+        else
+        {
+            ZV_G16_COL(aA, 0, 0, false)
+            if (more) issue_pa(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aA, 0, 1, false)
+            ZV_G16_COL(aA, 0, 2, false)
+            if (more) issue_pb(0);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aA, 0, 3, false)
+            if constexpr (EXTRA)
+            {
+                accx[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axA, bxc[0], accx[0][0], 0, 0, 0);
+                accx[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axA, bxc[1], accx[0][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next half's first fragments (visible since this iteration's barrier), under the last sixteen MFMAs
+        if (h + 1 < nhalf) ZV_G16_READ0(h + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (h == 0)
+        {
+            ZV_G16_COL(aB, 4, 0, true)
+            if (more) issue_pa(1);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aB, 4, 1, true)
+            ZV_G16_COL(aB, 4, 2, true)
+            ZV_G16_COL(aB, 4, 3, true)
+            if constexpr (EXTRA)
+            {
+                accx[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axB, bxc[0], zero4, 0, 0, 0);
+                accx[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axB, bxc[1], zero4, 0, 0, 0);
+            }
+        }
+        else
+        {
+            ZV_G16_COL(aB, 4, 0, false)
+            if (more) issue_pa(1);
+            __builtin_amdgcn_sched_barrier(0);
+            ZV_G16_COL(aB, 4, 1, false)
+            ZV_G16_COL(aB, 4, 2, false)
+            ZV_G16_COL(aB, 4, 3, false)
+            if constexpr (EXTRA)
+            {
+                accx[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axB, bxc[0], accx[1][0], 0, 0, 0);
+                accx[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axB, bxc[1], accx[1][1], 0, 0, 0);
+            }
+        }
+        if (more)
+        {
+            issue_pb(1);
+            issue_x();
+        }
+#undef ZV_G16_COL
+    }
+#undef ZV_G16_READ0
+
+    // ---- epilogue: bias, residual, scale, activation, f32 store, InstanceNorm partial sums (as conv1d_mfma_kernel), on a
+    // 32-row x 32-channel block = row tiles (tA, tB) x the channel pair (2c, 2c + 1) of the block's two column tiles
+    const int Cout_p = J.Cout_p;
+    const float escale = J.escale;
+    const bool has_res = J.res != nullptr;
+    const float *res = has_res ? J.res + row0 * J.ldres : nullptr;
+    float *out = (float *)J.out + row0 * J.ldo;
+    // c0[i], c1[i]: rows 4g + i of the block's first 16-row tile; d0, d1: of its second; channels oc, oc + 1
+    auto finish_block = [&](const floatx4 &c0, const floatx4 &c1, const floatx4 &d0, const floatx4 &d1, int t_first, int oc, int blk) {
+        if (oc >= Cout_p) return;
+        const float2 bias = J.bias ? *(const float2 *)(J.bias + oc) : make_float2(0.f, 0.f);
+        float2v resv[2][4];
+        if (has_res)
+        {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int t = t_first + 16 * hf + 4 * lg + i;
+                    resv[hf][i] = *(const float2v *)(res + (size_t)(t < L ? t : L - 1) * J.ldres + oc);
+                }
+        }
+        float outv[2][2][4];        // [channel][row half][i]
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int t = t_first + 16 * hf + 4 * lg + i;
+                float v0 = (hf ? d0[i] : c0[i]) + bias.x, v1 = (hf ? d1[i] : c1[i]) + bias.y;
+                if (has_res)
+                {
+                    v0 = v0 + resv[hf][i][0];
+                    v1 = v1 + resv[hf][i][1];
+                }
+                v0 = v0 * escale;
+                v1 = v1 * escale;
+                if (J.eact)
+                {
+                    v0 = lrelu(v0, J.oslope);
+                    v1 = lrelu(v1, J.oslope);
+                }
+                outv[0][hf][i] = v0;
+                outv[1][hf][i] = v1;
+                if (t < L)
+                {
+                    const float2v o = {v0, v1};
+                    __builtin_nontemporal_store(o, (float2v *)(out + (size_t)t * J.ldo + oc));
+                }
+            }
+        if (J.stat_part && oc < J.stat_C && blk * 32 < L)
+        {
+            // tile_stats_store's order: per channel two sequential f64 chains — rows 0-3, 8-11, 16-19, 24-27 (lane groups 0, 2, 0, 2)
+            // and rows 4-7, 12-15, 20-23, 28-31 (groups 1, 3, 1, 3) — added at the end.  A chain walks from group g to g + 2 and back.
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+            {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int st = 0; st < 4; st++)          // stage: row half st >> 1, lane groups {0, 1} (even stages) / {2, 3} (odd)
+                {
+                    if (st)
+                    {
+                        s1 = __shfl_xor(s1, 32, 64);
+                        s2 = __shfl_xor(s2, 32, 64);
+                    }
+                    if ((lg >> 1) == (st & 1))
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                        {
+                            const int t = t_first + 16 * (st >> 1) + 4 * lg + i;
+                            const double x = (t < L) ? (double)outv[ch][st >> 1][i] : 0.0;
+                            s1 += x;
+                            s2 += x * x;
+                        }
+                }
+                // lane groups 2 and 3 hold the two chains
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                if (lg == 2) *(double2 *)(J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc + ch) * 2) = make_double2(s1, s2);
+            }
+        }
+    };
+    const int tbase = m0 + wm * 128;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int b4 = 0; b4 < 4; b4++)
+            finish_block(acc[2 * b4][2 * p], acc[2 * b4][2 * p + 1], acc[2 * b4 + 1][2 * p], acc[2 * b4 + 1][2 * p + 1], tbase + b4 * 32,
+                         ((g * 8 + wn * 2 + p) << 5) + 2 * lc, (m0 >> 5) + wm * 4 + b4);
+    if constexpr (EXTRA)
+        finish_block(accx[0][0], accx[0][1], accx[1][0], accx[1][1], m0 + wave * 32, ((g * 8 + 8) << 5) + 2 * lc, (m0 >> 5) + wave);
+}
+
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvJobs jobs)
 {
     const ConvJob &J = jobs.j[0];
@@ -4275,6 +4635,31 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvJobs jobs)
         conv_gemm_body<false>(jobs, g, rt);
 }
 
+__global__ __launch_bounds__(512, 2) void conv_gemm16_kernel(const ConvJobs jobs)
+{
+    const ConvJob &J = jobs.j[0];
+    const int ng = (gemm_groups_dev(J.Cout_p));
+    const int rts = jobs.tps * jobs.segs.nseg;
+    int g, rt;
+    if (jobs.order == 2 && ng > 1)
+    {
+        // longest jobs first (see conv_gemm_kernel)
+        if ((int)blockIdx.x < rts) { g = ng - 1; rt = blockIdx.x; }
+        else { const int b2 = blockIdx.x - rts; g = b2 % (ng - 1); rt = b2 / (ng - 1); }
+    }
+    else
+    {
+        g = blockIdx.x % ng;
+        rt = blockIdx.x / ng;
+    }
+    if (rt >= rts) return;
+    const bool ninth = g == ng - 1 && ((J.Cout_p + 31) >> 5) - 8 * ng == 1;
+    if (ninth)
+        conv_gemm16_body<true>(jobs, g, rt);
+    else
+        conv_gemm16_body<false>(jobs, g, rt);
+}
+
 static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs &segs, int rate)
 {
     ConvJobs js;
@@ -4295,6 +4680,13 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
     // (per launch, like every other launcher here: the attribute is stored per device)
     hipError_t e = hipFuncSetAttribute((const void *)conv_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
+    if (knob(ZV_PAIR16) != 0 && job.w8x && js.order != 1)
+    {   // the 16 x 16 x 32 form (same bits; ZV_PAIR16 = 0: the 32 x 32 x 16 form)
+        e = hipFuncSetAttribute((const void *)conv_gemm16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_gemm16_kernel, grid, dim3(512), lds, s, js);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(512), lds, s, js);
     return hipGetLastError();
 }

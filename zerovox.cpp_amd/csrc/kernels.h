@@ -103,6 +103,7 @@ struct ConvJob
     // weights packed in MFMA-fragment order (see pack_conv_weight), bias padded to 32*ntiles
     const void  *w;
     const void  *w8;             // the same weights in conv_gemm_kernel's stream order (pack_conv_weight_gemm), or null
+    const void  *w8x;            // ... in conv_gemm16_kernel's (pack_conv_weight_gemm16: 16 x 16 x 32 fragments), or null
     const float *bias;
     // epilogue: v = acc + bias; v += res; v *= escale; v = lrelu(v, oslope) if eact; store f32 | f16
     const float *res;
@@ -150,6 +151,7 @@ int    conv_gemm_tiles(int Cout_p);         // output tiles conv_gemm_kernel cov
 int    conv_gemm_units(int Cin_p, int K);
 size_t conv_gemm_weight_halfs(int Cin_p, int Cout_p, int K);
 void   pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst);
+void   pack_conv_weight_gemm16(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst);
 // all jobs of one launch share the segments, Cout_p and the tile configuration; job.L is ignored (rows come from segs)
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 

@@ -68,6 +68,9 @@ ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::s
         pack_conv_weight_gemm((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, p8.data());
         c.w8 = dev_alloc(p8.size() * 2);
         ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
+        pack_conv_weight_gemm16((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, p8.data());
+        c.w8x = dev_alloc(p8.size() * 2);
+        ZV_HIP(hipMemcpy(c.w8x, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
     }
     if (!bname.empty())
     {
@@ -143,6 +146,9 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
         pack_conv_weight_gemm(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, p8.data());
         c.w8 = dev_alloc(p8.size() * 2);
         ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
+        pack_conv_weight_gemm16(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, p8.data());
+        c.w8x = dev_alloc(p8.size() * 2);
+        ZV_HIP(hipMemcpy(c.w8x, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
     }
     snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.b", idx);
     const GgufTensor &b = g.get(nm);
@@ -778,6 +784,7 @@ ConvJob Model::job(const ConvW &w) const
     j.ck = w.ck;
     j.w = w.w;
     j.w8 = w.w8;
+    j.w8x = w.w8x;
     j.bias = w.bias;
     j.pro = PRO_ACT;
     j.slope = 1.0f;

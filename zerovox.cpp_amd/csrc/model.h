@@ -22,6 +22,7 @@ struct ConvW
 {
     void  *w = nullptr;
     void  *w8 = nullptr;        // conv_gemm_kernel's stream order (wide decoder convs), or null
+    void  *w8x = nullptr;       // conv_gemm16_kernel's (16 x 16 x 32 fragments), or null
     float *bias = nullptr;
     int    K = 0, Cin = 0, Cout = 0, Cin_p = 0, Cout_p = 0, ck = 0;
 };
