@@ -231,13 +231,10 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       ("block64_3_no_merge", {"ZV_BLOCK64": "-3", "ZV_PAIR64_RING": "2"}), ("block64_11", {"ZV_BLOCK64": "-11", "ZV_PAIR64_RING": "2"}),
                       ("no_block64", {"ZV_BLOCK64": "0", "ZV_PAIR64_RING": "2"}),
                       ("upsample_stream", {"ZV_CONV_STREAM": "2"}), ("upsample_no_stream", {"ZV_CONV_STREAM": "0"}),
-                      # round 4: the fused pair kernel on v_mfma_f32_16x16x32_f16 (default) against its 32x32x16 form — and, through
-                      # "no_fuse" above, against the generic conv kernel's 32x32x16 chains: one k-ordered chain, two instruction shapes
-                      ("pair_32x32x16", {"ZV_PAIR16": "0"}), ("pair_32x32x16_fuse256_merge", {"ZV_PAIR16": "0", "ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1"}),
-                      ("pair_32x32x16_merge_one_wg", {"ZV_PAIR16": "0", "ZV_FUSE256": "1", "ZV_MERGE_ALWAYS": "1", "ZV_MERGE_SEQ": "0"}),
-                      ("pair_mt4", {"ZV_PAIR_MT": "4", "ZV_FUSE256": "1"}), ("pair_mt4_32x32x16", {"ZV_PAIR_MT": "4", "ZV_FUSE256": "1", "ZV_PAIR16": "0"}),
-                      ("pair_no_ring_no_triple", {"ZV_PAIR64_RING": "0", "ZV_NO_TRIPLE": "1", "ZV_MERGE_ALWAYS": "1"}),
-                      ("pair_no_ring_no_triple_32x32x16", {"ZV_PAIR64_RING": "0", "ZV_NO_TRIPLE": "1", "ZV_MERGE_ALWAYS": "1", "ZV_PAIR16": "0"})):
+                      # round 4: the fused batch kernels run on v_mfma_f32_16x16x32_f16, the generic conv kernel ("no_fuse") and the
+                      # single-utterance whole-block kernel on 32x32x16: one k-ordered chain, two instruction shapes, the same bits
+                      ("pair_mt4", {"ZV_PAIR_MT": "4", "ZV_FUSE256": "1"}),
+                      ("pair_no_ring_no_triple", {"ZV_PAIR64_RING": "0", "ZV_NO_TRIPLE": "1", "ZV_MERGE_ALWAYS": "1"})):
         with capi.switches(**{k: int(v) for k, v in env.items()}):      # some switches are sampled when the model is built, some at every launch
             m = capi.Model(path, 0)
             outs[name] = m.vocode(mel)

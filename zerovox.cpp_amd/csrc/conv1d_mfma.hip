@@ -1268,208 +1268,9 @@ __device__ __forceinline__ void stage_act_buf(__amdgpu_buffer_rsrc_t rsrc, char 
 // and stores only (out_0 + out_1) + out_2 — the sum the next layer starts with (reference src/hifigan.cpp:300-315) — so the
 // branch outputs of a stage's last dilation pair never reach HBM and the consumer reads one tensor instead of three.  The
 // tile height is that of the job with the most taps (a few rows of extra halo for the others).
-template <int CP, int MT, bool MERGE>
-__global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
-{
-    constexpr int NT = (CP == 256) ? 2 : 1;            // output tiles of 32 channels per wave
-    constexpr int WN = CP / 32 / NT, WM = 4 / WN;
-    constexpr int BM = 32 * MT * WM;
-    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
-    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
-    // workgroup -> (segment, time tile): every segment gets the tile count of the longest one, tiles past a segment's
-    // end exit; the XCD map runs over the whole (segment, tile) range, so an XCD works on neighbouring tiles of
-    // neighbouring utterances
-    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
-    if (vt >= tps * jobs.segs.nseg) return;
-    const int useg = vt / tps;
-    const Seg sg = seg_at(jobs.segs, useg);
-    const int L = sg.rows * jobs.rate;
-    const int t0 = (vt - useg * tps) * TM;
-    if (t0 >= L) return;
-#ifdef ZV_STAMPS
-    const int stamp_wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
-    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
-    {
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 9] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 10] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    ZV_STAMP(0)
-    floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
-    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
-    {
-    const PairJob &P = jobs.j[jb];
-    const int K = P.K, dil = P.dil;
-    const int h2 = (K - 1) / 2, h1 = h2 * dil;
-    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-    float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
-    if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the LDS tile
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const size_t wseg = (size_t)(round_up(K * NKC, 4) + 8) * 64;        // half8 units per n-tile segment
-
-
-    // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r   (+ dil rows: the zero-weight tap of CP = 32 must read finite data)
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
-    // every staging load of the tile is in flight before the first one is consumed (one HBM round trip instead of one
-    // per batch of four: measured 6.7 of a workgroup's 20.5 us at 64 channels)
-    // (the merged variant holds the running sum of the branches: it keeps the short batches and its occupancy)
-    // (the wide stages: phase stamps, round 3 — with 4 pieces in flight a 128-channel tile took 6 round trips = 9.7 us of a
-    // workgroup's 35, a 256-channel tile 10 = 16 us of 82; the staging registers are dead before the accumulators live, so
-    // 12 / 19 in flight cost no occupancy)
-    constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : (CP == 128 ? ZV_STAGE_U128 : ZV_STAGE_U256)));
-    // (the wide stages keep their registers for occupancy: their first fragments are requested right before the loops)
-    constexpr bool EARLY_B = CP <= 64 && !MERGE;
-    half8 bw[4][NT];
-    if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
-    if (!(ZV_DBGBITS(P.dbg) & 1)) stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
-    ZV_STAMP(1)
-    __syncthreads();
-    ZV_STAMP(2)
-
-    const char *abase = smem + (wm * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-    floatx16 acc[MT][NT];
-    if (ZV_DBGBITS(P.dbg) & 2)          // timing ablation only: the MFMA loops (which start the accumulators from 0) are skipped
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int n = 0; n < NT; n++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
-
-    // ---- conv1 (dilated), transposed product: acc[mt][4q+j] = xt_pre[time = .. + (lane&31)][oc = wn*32 + 8q + 4h + j]
-    if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
-    if (!(ZV_DBGBITS(P.dbg) & 2)) mfma_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw, (ZV_DBGBITS(P.dbg) & 32) ? 0 : 8 * 64);
-    if constexpr (EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
-    ZV_STAMP(3)
-    __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
-    ZV_STAMP(4)
-
-    // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
-    {
-        const int hh = lane >> 5;
-        const float sl = P.slope;
-        // only the first and the last tile of a segment hold rows outside [0, L): interior tiles skip the masking
-        const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-        {
-            const int ocb = (wn * NT + nt) * 32;
-            float4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + ocb + 8 * q + 4 * hh);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-            {
-                const int i = wm * 32 * MT + mt * 32 + (lane & 31);
-                const int t = t0 - h2 + i;
-                const bool in = !edge || (t >= 0 && t < L);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                {
-                    half4 h;
-                    h[0] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 0] + bq[q].x, sl);
-                    h[1] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 1] + bq[q].y, sl);
-                    h[2] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 2] + bq[q].z, sl);
-                    h[3] = (_Float16)lrelu_max(acc[mt][nt][4 * q + 3] + bq[q].w, sl);
-                    uint2 pk = *(uint2 *)&h;
-                    if (edge)
-                    {
-                        pk.x = in ? pk.x : 0u;
-                        pk.y = in ? pk.y : 0u;
-                    }
-                    *(uint2 *)(smem + i * RS + (ocb + 8 * q + 4 * hh) * 2) = pk;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    ZV_STAMP(5)
-
-    // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-    if constexpr (!EARLY_B) deep_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);
-    if (!(ZV_DBGBITS(P.dbg) & 2)) mfma_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw, (ZV_DBGBITS(P.dbg) & 32) ? 0 : 8 * 64);
-
-    // ---- epilogue: out = y + (conv2 + b2).  Buffer descriptors over exactly this tile's valid rows: row >= TM or
-    // time >= L is out of range (loads give 0, stores are dropped) and every access is one instruction with a
-    // per-lane offset computed once and a scalar row offset — no address arithmetic, no predicates.
-    ZV_STAMP(6)
-    if (ZV_DBGBITS(P.dbg) & 4) return;
-    const int nrows = (L - t0 < TM) ? (L - t0) : TM;
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-    float *const outp = (!MERGE && P.sum_out) ? P.sum_out + (size_t)sg.row0 * jobs.rate * CP : out_seg;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(outp + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_sum = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((P.sum_in ? P.sum_in : y_seg) + (P.sum_in ? (size_t)sg.row0 * jobs.rate * CP : 0) + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-    {
-        const int oc = (wn * NT + nt) * 32 + (lane & 31);
-        const float bias = P.b2[oc];
-        const int voff = ((wm * 32 * MT + 4 * (lane >> 5)) * CP + oc) * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-        {
-            float resv[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                resv[r] = (ZV_DBGBITS(P.dbg) & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
-            if (ZV_DBGBITS(P.dbg) & 16) continue;
-            if constexpr (MERGE)
-            {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                {
-                    const float v = (acc[mt][nt][r] + bias) + resv[r];
-                    msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
-                }
-                if (jb == jobs.njobs - 1)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(msum[mt][nt][r]), rs_out, voff,
-                                                              (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
-            }
-            else if (P.sum_out)
-            {
-                // this branch's term of the MRF sum: sum_out = sum_in + v (the first branch stores v itself)
-                float sumv[16];
-                if (P.sum_in)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        sumv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sum, voff, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                {
-                    const float v = (acc[mt][nt][r] + bias) + resv[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(P.sum_in ? sumv[r] + v : v), rs_out, voff,
-                                                          (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[r]), rs_out, voff,
-                                                          (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
-            }
-        }
-    }
-#ifdef ZV_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    ZV_STAMP(7)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The same fused dilation pair on v_mfma_f32_16x16x32_f16 (round 4).
+//
+// The kernel runs on v_mfma_f32_16x16x32_f16 (round 4; rounds 1-3: 32x32x16, whose MFMA loop — mfma_taps_deep above — the
+// single-utterance whole-block kernel resblock_triple_kernel still uses).
 //
 // The two f16 MFMA shapes give the SAME BITS for one k-ordered accumulation chain: a chain walked 16 products per instruction
 // (32x32x16) equals the same chain walked 32 per instruction (16x16x32) — measured on 204 800 random elements at three scales,
@@ -1621,7 +1422,7 @@ __device__ __forceinline__ void mfma16_taps_deep(floatx4 (&acc)[MT][NT][2][2], c
 }
 
 template <int CP, int MT, bool MERGE>
-__global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairJobs jobs)
+__global__ __launch_bounds__(256) void resblock_pair_kernel(const PairJobs jobs)
 {
     constexpr int NT = (CP == 256) ? 2 : 1;            // output tiles of 32 channels per wave
     constexpr int WN = CP / 32 / NT, WM = 4 / WN;
@@ -1660,7 +1461,7 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairJobs job
     constexpr int STAGE_U = MERGE ? 4 : ((CP == 32) ? 10 : (CP == 64 ? 12 : (CP == 128 ? ZV_STAGE_U128 : ZV_STAGE_U256)));
     constexpr bool EARLY_B = CP <= 64 && !MERGE;
     half8 bw[2][NT][2];
-    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg);
+    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
     stage_act_buf<STAGE_U, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
     __syncthreads();
 
@@ -1669,9 +1470,9 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairJobs job
     floatx4 acc[MT][NT][2][2];
 
     // ---- conv1 (dilated), transposed product: acc[mt][nt][wt][lt][i] = xt_pre[time = mt*32 + 2c + lt][oc = 16 wt + 4g + i]
-    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg);
-    mfma16_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1x + wn * NT * wseg + lane, wseg, K, bw);
-    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
+    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg);
+    mfma16_taps_deep<CP, MT, NT, true>(acc, abase, dil * RS, (const half8 *)P.w1 + wn * NT * wseg + lane, wseg, K, bw);
+    if constexpr (EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);     // conv2's first fragments travel under the xt pack
     __syncthreads();                       // every wave is done reading X: its LDS region becomes XT
 
     // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
@@ -1715,8 +1516,8 @@ __global__ __launch_bounds__(256) void resblock_pair16_kernel(const PairJobs job
     __syncthreads();
 
     // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg);
-    mfma16_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2x + wn * NT * wseg + lane, wseg, K, bw);
+    if constexpr (!EARLY_B) deep16_preload_b<NT>(bw, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg);
+    mfma16_taps_deep<CP, MT, NT, false>(acc, abase, RS, (const half8 *)P.w2 + wn * NT * wseg + lane, wseg, K, bw);
 
     // ---- epilogue: out = y + (conv2 + b2).  acc[mt][nt][wt][lt][i] = time row mt*32 + 8g + 2i + lt, channel 2c + wt: the lane's two
     // weight tiles are neighbouring channels -> 8-byte accesses, four rows x 128 bytes per instruction.  Buffer descriptors over
@@ -1802,21 +1603,25 @@ extern "C" int zv_debug_read_stamps(unsigned long long *out, size_t n)
 // Weight layout (pack_pair_weight_ring): [tap][kc][ntile][lane][8 halfs].
 size_t pair_ring_weight_halfs(int Cp, int K) { return (size_t)K * (Cp / 16) * (Cp / 32) * 512; }
 
-void pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst)
+// the ring stream in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair64_kernel / resblock_block64_kernel): [tap][step of 32
+// channels][ntile][wt][lane][8 halfs]; conv2_layout as in pack_pair_weight16
+void pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout)
 {
-    const int nkc = Cp / 16, nnt = Cp / 32;
+    const int nk2 = Cp / 32, nnt = Cp / 32;
     for (int tap = 0; tap < K; tap++)
-        for (int kc = 0; kc < nkc; kc++)
+        for (int k2 = 0; k2 < nk2; k2++)
             for (int nt = 0; nt < nnt; nt++)
-            {
-                uint16_t *d = dst + ((size_t)(tap * nkc + kc) * nnt + nt) * 512;
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++)
-                    {
-                        const int oc = nt * 32 + (lane & 31), ic = kc * 16 + 8 * (lane >> 5) + j;
-                        d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
-                    }
-            }
+                for (int wt = 0; wt < 2; wt++)
+                {
+                    uint16_t *d = dst + ((((size_t)(tap * nk2 + k2) * nnt + nt) * 2) + wt) * 512;
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++)
+                        {
+                            const int r = lane & 15, g = lane >> 4;
+                            const int oc = nt * 32 + (conv2_layout ? 2 * r + wt : 16 * wt + r), ic = k2 * 32 + 8 * g + j;
+                            d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
+                        }
+                }
 }
 
 template <bool MERGE>
@@ -1849,289 +1654,8 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64_kernel(const PairJobs 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-    const char *bl = ring + lane * 16;
-
-    floatx16 msum[MERGE ? MT : 1][MERGE ? NT : 1];
-    for (int jb = MERGE ? 0 : jz; jb < (MERGE ? jobs.njobs : jz + 1); jb++)
-    {
-        const PairJob &P = jobs.j[jb];
-        const int K = P.K, dil = P.dil;
-        const int h2 = (K - 1) / 2, h1 = h2 * dil;
-        const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-        float *out_seg = (MERGE ? jobs.merge_out : P.out) + (size_t)sg.row0 * jobs.rate * CP;
-        const int nchunk = 2 * K;
-        // chunk g of the pair's weight stream (conv1's taps, then conv2's) -> ring slot g & 3; a wave moves 2 of its 8 fragments
-        // (the stream's base pointers pinned in scalar registers: re-reading them from the kernel arguments at every request
-        // would put an lgkmcnt(0) wait — which also waits for the LDS reads in flight — into every tap)
-        const uint64_t w1a = (uint64_t)P.w1r + wave * 2048, w2a = (uint64_t)P.w2r + wave * 2048 - (uint64_t)K * CHUNK;
-        const uint32_t w1lo = __builtin_amdgcn_readfirstlane((uint32_t)w1a), w1hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1a >> 32));
-        const uint32_t w2lo = __builtin_amdgcn_readfirstlane((uint32_t)w2a), w2hi = __builtin_amdgcn_readfirstlane((uint32_t)(w2a >> 32));
-        auto issue = [&](int g) {
-            const uint64_t base = g < K ? ((uint64_t)w1hi << 32 | w1lo) : ((uint64_t)w2hi << 32 | w2lo);
-            const char *src = (const char *)base + (size_t)g * CHUNK + lane * 16;
-            char *dst = ring + (g & 3) * CHUNK + wave * 2048;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
-        };
-        if (MERGE && jb) __syncthreads();               // the previous job's conv2 is done reading the tile and the ring
-        issue(0);
-        issue(1);
-        issue(2);
-
-        // ---- stage X: LDS row r <-> time t0 - h2 - h1 + r
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
-        // (two workgroups per CU whatever the register count — LDS decides — so every staging load of the tile is in flight at once)
-        if (!(ZV_DBGBITS(P.dbg) & 1)) stage_act_buf<20, CP>(rs_y, smem, t0 - h2 - h1, BM + 2 * h1 + dil, tid, P.slope);
-        // the residual operand (the tile's centre rows again, in the accumulator layout) is requested right behind the
-        // staging loads, while their lines are still in L2, and waits in registers until the epilogue
-        const int nrows = (L - t0 < TM) ? (L - t0) : TM;
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(y_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-        const int voff0 = ((wave * 32 * MT + 4 * (lane >> 5)) * CP + (lane & 31)) * 4;
-        float resv[MT][NT][16];
-        auto load_res = [&]() {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        resv[mt][nt][r] = (ZV_DBGBITS(P.dbg) & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, voff0 + nt * 128, (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0));
-        };
-        if constexpr (!MERGE) load_res();      // (the merged form holds the branches' running sum: it loads in the epilogue)
-        ZV_STAMP(1)
-        __syncthreads();                                // X complete; the barrier drains the first three chunks too
-        ZV_STAMP(2)
-
-        floatx16 acc[MT][NT];
-        half8 a[4][MT], b[4][NT];
-        int g = 0;                                      // chunk = tap of the stream
-#define ZV_LDR(slot, aptr, boff)                                                                                      \
-    {                                                                                                                 \
-        const char *ap_ = (aptr);                                                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = ZV_ABL_LD(a[slot], ap_, mt);                  \
-        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[slot][nt] = *(const half8 *)(bp_ + (boff) + nt * 1024);  \
-    }
-#define ZV_MF(slot, SW, Z)                                \
-    mfma_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);      \
-    __builtin_amdgcn_sched_barrier(0);
-        // one tap: steps 0, 1 | wait for the next chunk, barrier, request the chunk three ahead | steps 2, 3 (which already
-        // read the next tap's first fragments)
-#define ZV_TAP(SW, Z0, tapstride)                                                                         \
-    {                                                                                                     \
-        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
-        ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
-        ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
-        if (!(ZV_DBGBITS(P.dbg) & 64)) {                                                                              \
-        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                           \
-        if (!(ZV_DBGBITS(P.dbg) & 128)) __builtin_amdgcn_s_barrier();                                                 \
-        if (g + 3 < nchunk) issue(g + 3);                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        ap += (tapstride);                                                                                \
-        bp_ = bn_;                                                                                        \
-        ZV_LDR(0, ap, 0) ZV_MF(2, SW, false)                                                              \
-        ZV_LDR(1, ap + 32, 2 * 1024) ZV_MF(3, SW, false)                                                  \
-        g++;                                                                                              \
-    }
-        // ---- conv1 (dilated), transposed product
-        if (ZV_DBGBITS(P.dbg) & 2)
-        {
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int n = 0; n < NT; n++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[i][n][r] = 0.f;
-            // keep the weight stream's protocol (barriers, requests) without the MFMAs
-            for (int tap = 0; tap < K; tap++)
-            {
-                if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (g + 3 < nchunk) issue(g + 3);
-                g++;
-            }
-        }
-        else
-        {
-            const char *ap = abase;
-            {
-                const char *bp_ = bl;
-                ZV_LDR(0, ap, 0)
-                ZV_LDR(1, ap + 32, 2 * 1024)
-            }
-            ZV_TAP(true, true, dil * RS)
-            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
-        }
-        ZV_STAMP(3)
-        // every wave is done reading X: its LDS region becomes XT (raw barriers here: __syncthreads would drain the weight
-        // stream, whose next chunks are in flight under the pack)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        ZV_STAMP(4)
-        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L); XT row i <-> time t0 - h2 + i
-        {
-            const int hh = lane >> 5;
-            const float sl = P.slope;
-            const bool edge = t0 - h2 < 0 || t0 - h2 + BM > L;
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-            {
-                float4 bq[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(P.b1 + nt * 32 + 8 * q + 4 * hh);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                {
-                    const int i = wave * 32 * MT + mt * 32 + (lane & 31);
-                    const int t = t0 - h2 + i;
-                    const bool in = !edge || (t >= 0 && t < L);
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                    {
-                        uint2 pk = lrelu4_f16(acc[mt][nt][4 * q + 0] + bq[q].x, acc[mt][nt][4 * q + 1] + bq[q].y,
-                                              acc[mt][nt][4 * q + 2] + bq[q].z, acc[mt][nt][4 * q + 3] + bq[q].w, sl);
-                        if (edge)
-                        {
-                            pk.x = in ? pk.x : 0u;
-                            pk.y = in ? pk.y : 0u;
-                        }
-                        *(uint2 *)(smem + i * RS + (nt * 32 + 8 * q + 4 * hh) * 2) = pk;
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        ZV_STAMP(5)
-        // ---- conv2 (dil 1): output row j <-> time t0 + j reads XT rows j .. j + 2*h2; rows j >= TM are discarded
-        if (ZV_DBGBITS(P.dbg) & 2)
-        {
-            for (int tap = 0; tap < K; tap++)
-            {
-                if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (g + 3 < nchunk) issue(g + 3);
-                g++;
-            }
-        }
-        else
-        {
-            const char *ap = abase;
-            {
-                const char *bp_ = bl + (g & 3) * CHUNK;
-                ZV_LDR(0, ap, 0)
-                ZV_LDR(1, ap + 32, 2 * 1024)
-            }
-            ZV_TAP(false, true, RS)
-            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
-        }
-#undef ZV_TAP
-#undef ZV_MF
-#undef ZV_LDR
-
-        // ---- epilogue: out = y + (conv2 + b2); descriptors over exactly this tile's valid rows (see resblock_pair_kernel)
-        ZV_STAMP(6)
-        if (ZV_DBGBITS(P.dbg) & 4) return;
-        if constexpr (MERGE) load_res();
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(out_seg + (size_t)t0 * CP), 0, nrows * CP * 4, 0x00020000);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-        {
-            const int oc = nt * 32 + (lane & 31);
-            const float bias = P.b2[oc];
-            const int voff = voff0 + nt * 128;
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-            {
-                if (ZV_DBGBITS(P.dbg) & 16) continue;
-                if constexpr (MERGE)
-                {
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                    {
-                        const float v = (acc[mt][nt][r] + bias) + resv[mt][nt][r];
-                        msum[mt][nt][r] = jb == 0 ? v : msum[mt][nt][r] + v;
-                    }
-                    if (jb == jobs.njobs - 1)
-#pragma unroll
-                        for (int r = 0; r < 16; r++)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(msum[mt][nt][r]), rs_out, voff,
-                                                                  (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
-                }
-                else
-                {
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[mt][nt][r] + bias) + resv[mt][nt][r]), rs_out, voff,
-                                                              (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, ZV_ST_AUX);
-                }
-            }
-        }
-#ifdef ZV_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        ZV_STAMP(7)
-    }
-}
-
-// the ring stream in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair64x_kernel / resblock_block64x_kernel): [tap][step of 32
-// channels][ntile][wt][lane][8 halfs]; conv2_layout as in pack_pair_weight16
-void pack_pair_weight_ring16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout)
-{
-    const int nk2 = Cp / 32, nnt = Cp / 32;
-    for (int tap = 0; tap < K; tap++)
-        for (int k2 = 0; k2 < nk2; k2++)
-            for (int nt = 0; nt < nnt; nt++)
-                for (int wt = 0; wt < 2; wt++)
-                {
-                    uint16_t *d = dst + ((((size_t)(tap * nk2 + k2) * nnt + nt) * 2) + wt) * 512;
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int j = 0; j < 8; j++)
-                        {
-                            const int r = lane & 15, g = lane >> 4;
-                            const int oc = nt * 32 + (conv2_layout ? 2 * r + wt : 16 * wt + r), ic = k2 * 32 + 8 * g + j;
-                            d[lane * 8 + j] = (oc < C && ic < C) ? w[((size_t)oc * C + ic) * K + tap] : (uint16_t)0;
-                        }
-                }
-}
-
-template <bool MERGE>
-__global__ __launch_bounds__(256, 2) void resblock_pair64x_kernel(const PairJobs jobs)
-{
-    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
-    constexpr int CHUNK = 8 * 1024;                  // one tap: 4 channel steps x 2 output tiles
-    const int jz = (int)blockIdx.z, bx = (int)blockIdx.x;
-    const int TM = BM - (MERGE ? jobs.kmax - 1 : jobs.j[jz].K - 1);
-    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
-    if (vt >= tps * jobs.segs.nseg) return;
-    const int useg = vt / tps;
-    const Seg sg = seg_at(jobs.segs, useg);
-    const int L = sg.rows * jobs.rate;
-    const int t0 = (vt - useg * tps) * TM;
-    if (t0 >= L) return;
-
-#ifdef ZV_STAMPS
-    const int stamp_wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
-    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)
-    {
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 8] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
-        zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + 9] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
-    }
-#endif
-    ZV_STAMP(0)
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char *ring = smem + jobs.ring_off;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lg = lane >> 4;
-    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair16_kernel)
+    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair_kernel)
     const char *bl = ring + lane * 16;
 
     floatx4 msum[MERGE ? MT : 1][MERGE ? NT : 1][2][2];
@@ -2146,7 +1670,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair64x_kernel(const PairJobs
         // chunk g of the pair's weight stream (conv1's taps, then conv2's) -> ring slot g & 3; a wave moves 2 of its 8 fragments
         // (the stream's base pointers pinned in scalar registers: re-reading them from the kernel arguments at every request
         // would put an lgkmcnt(0) wait — which also waits for the LDS reads in flight — into every tap)
-        const uint64_t w1a = (uint64_t)P.w1rx + wave * 2048, w2a = (uint64_t)P.w2rx + wave * 2048 - (uint64_t)K * CHUNK;
+        const uint64_t w1a = (uint64_t)P.w1r + wave * 2048, w2a = (uint64_t)P.w2r + wave * 2048 - (uint64_t)K * CHUNK;
         const uint32_t w1lo = __builtin_amdgcn_readfirstlane((uint32_t)w1a), w1hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1a >> 32));
         const uint32_t w2lo = __builtin_amdgcn_readfirstlane((uint32_t)w2a), w2hi = __builtin_amdgcn_readfirstlane((uint32_t)(w2a >> 32));
         auto issue = [&](int g) {
@@ -2337,15 +1861,11 @@ static hipError_t launch_pair64_ring(hipStream_t s, PairJobs &js, int njobs, int
     js.ring_off = round_up((BM + Kmax * dmax) * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
     if (lds > 80 * 1024) return hipErrorInvalidValue;
-    bool x16 = knob(ZV_PAIR16) != 0;          // the 16 x 16 x 32 form wherever its weight stream exists (same bits)
-    for (int i = 0; i < njobs; i++) x16 = x16 && js.j[i].w1rx && js.j[i].w2rx;
-    auto launch = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
-        return hipGetLastError();
-    };
-    return x16 ? launch(resblock_pair64x_kernel<MERGE>) : launch(resblock_pair64_kernel<MERGE>);
+    auto kern = resblock_pair64_kernel<MERGE>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2386,232 +1906,8 @@ __global__ __launch_bounds__(256, 2) void resblock_block64_kernel(const TripleJo
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;
-    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + hh * 16;
-    const char *bl = ring + lane * 16;
-    const int nchunk = 2 * K * nd;                    // the block's weight stream: per pair conv1's taps, then conv2's
-    // chunk g -> ring slot g & 3; base pointers of the (at most six) convs in scalar registers
-    uint32_t wlo[2 * TRIPLE_MAX_DIL], whi[2 * TRIPLE_MAX_DIL];
-#pragma unroll
-    for (int c = 0; c < 2 * TRIPLE_MAX_DIL; c++)
-    {
-        const int d = c >> 1 < nd ? c >> 1 : 0;
-        const uint64_t a = (uint64_t)((c & 1) ? P.w2[d] : P.w1[d]) + wave * 2048;
-        wlo[c] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-        whi[c] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    }
-    auto issue = [&](int g) {
-        const int c = g / K, tap = g - c * K;         // conv index (2 * pair + conv), tap
-        uint32_t lo = wlo[0], hi = whi[0];
-#pragma unroll
-        for (int q = 1; q < 2 * TRIPLE_MAX_DIL; q++)
-            if (c == q) { lo = wlo[q]; hi = whi[q]; }
-        const char *src = (const char *)((uint64_t)hi << 32 | lo) + (size_t)tap * CHUNK + lane * 16;
-        char *dst = ring + (g & 3) * CHUNK + wave * 2048;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 1024), (__attribute__((address_space(3))) void *)(dst + 1024), 16, 0, 0);
-    };
-    issue(0);
-    issue(1);
-    issue(2);
-    // the whole operand region starts as zeros (margins stay zero for the whole kernel; nothing in it is ever uninitialised)
-    for (int i = tid; i < xrows * RS / 16; i += 256) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
-    // tile row i <-> time t0 - H + i; register [mt][nt][r]: row wave*64 + mt*32 + (r&3) + 8*(r>>2) + 4*hh, channel nt*32 + (lane&31)
-    float yreg[MT][NT][16];
-    {
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
-        const int voff = ((t0 - H + wave * 32 * MT + 4 * hh) * CP + (lane & 31)) * 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    yreg[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, voff + nt * 128 + (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
-    }
-    __syncthreads();                                  // zeros written (and the first chunks landed)
-    const float sl = P.slope;
-    int g = 0;
-    floatx16 acc[MT][NT];
-    half8 a[4][MT], b[4][NT];
-#define ZV_LDR(slot, aptr, boff)                                                                                      \
-    {                                                                                                                 \
-        const char *ap_ = (aptr);                                                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = *(const half8 *)(ap_ + mt * 32 * RS);         \
-        _Pragma("unroll") for (int nt = 0; nt < NT; nt++) b[slot][nt] = *(const half8 *)(bp_ + (boff) + nt * 1024);  \
-    }
-#define ZV_MF(slot, SW, Z)                                \
-    mfma_step<MT, NT, SW, Z>(acc, a[slot], b[slot]);      \
-    __builtin_amdgcn_sched_barrier(0);
-#define ZV_TAP(SW, Z0, tapstride)                                                                         \
-    {                                                                                                     \
-        const char *bp_ = bl + (g & 3) * CHUNK, *bn_ = bl + ((g + 1) & 3) * CHUNK;                        \
-        ZV_LDR(2, ap + 64, 4 * 1024) ZV_MF(0, SW, Z0)                                                     \
-        ZV_LDR(3, ap + 96, 6 * 1024) ZV_MF(1, SW, false)                                                  \
-        if (g + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-        __builtin_amdgcn_s_barrier();                                                                     \
-        if (g + 3 < nchunk) issue(g + 3);                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        ap += (tapstride);                                                                                \
-        bp_ = bn_;                                                                                        \
-        ZV_LDR(0, ap, 0) ZV_MF(2, SW, false)                                                              \
-        ZV_LDR(1, ap + 32, 2 * 1024) ZV_MF(3, SW, false)                                                  \
-        g++;                                                                                              \
-    }
-    for (int d = 0; d < nd; d++)
-    {
-        const int dil = P.dil[d], h1 = h2 * dil;
-        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + BM - 1 (Y is zero outside [0, L): so is X)
-        {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                    {
-                        const int i = wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        *(_Float16 *)(smem + (XM + i) * RS + (nt * 32 + (lane & 31)) * 2) = (_Float16)lrelu_max(yreg[mt][nt][r], sl);
-                    }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // (raw: the weight stream stays in flight)
-        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap * dil
-        {
-            const char *ap = abase + (XM - h1) * RS;
-            {
-                const char *bp_ = bl + (g & 3) * CHUNK;
-                ZV_LDR(0, ap, 0)
-                ZV_LDR(1, ap + 32, 2 * 1024)
-            }
-            ZV_TAP(true, true, dil * RS)
-            for (int tap = 1; tap < K; tap++) ZV_TAP(true, false, dil * RS)
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // every wave is done reading X: its rows become XT
-        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L)
-        {
-            const float *b1 = P.b1[d];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-            {
-                float4 bq[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(b1 + nt * 32 + 8 * q + 4 * hh);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                {
-                    const int i = wave * 32 * MT + mt * 32 + (lane & 31);
-                    const int t = t0 - H + i;
-                    const bool in = !edge || (t >= 0 && t < L);
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                    {
-                        uint2 pk = lrelu4_f16(acc[mt][nt][4 * q + 0] + bq[q].x, acc[mt][nt][4 * q + 1] + bq[q].y,
-                                              acc[mt][nt][4 * q + 2] + bq[q].z, acc[mt][nt][4 * q + 3] + bq[q].w, sl);
-                        if (edge)
-                        {
-                            pk.x = in ? pk.x : 0u;
-                            pk.y = in ? pk.y : 0u;
-                        }
-                        *(uint2 *)(smem + (XM + i) * RS + (nt * 32 + 8 * q + 4 * hh) * 2) = pk;
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        {
-            const char *ap = abase + (XM - h2) * RS;
-            {
-                const char *bp_ = bl + (g & 3) * CHUNK;
-                ZV_LDR(0, ap, 0)
-                ZV_LDR(1, ap + 32, 2 * 1024)
-            }
-            ZV_TAP(false, true, RS)
-            for (int tap = 1; tap < K; tap++) ZV_TAP(false, false, RS)
-        }
-        {
-            const float *b2 = P.b2[d];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-            {
-                const float bias = b2[nt * 32 + (lane & 31)];
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                    {
-                        const float v = (acc[mt][nt][r] + bias) + yreg[mt][nt][r];
-                        if (edge)
-                        {
-                            const int t = t0 - H + wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            yreg[mt][nt][r] = (t >= 0 && t < L) ? v : 0.f;
-                        }
-                        else
-                            yreg[mt][nt][r] = v;
-                    }
-            }
-        }
-        if (d + 1 < nd)
-        {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();             // every wave is done reading XT before the next X goes over it
-        }
-    }
-#undef ZV_TAP
-#undef ZV_MF
-#undef ZV_LDR
-    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int i = wave * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int t = t0 - H + i;
-                const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + nt * 32 + (lane & 31)) * 4 : -4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][nt][r]), rs_out, voff, 0, ZV_ST_AUX);
-            }
-}
-
-__global__ __launch_bounds__(256, 2) void resblock_block64x_kernel(const TripleJobs jobs)
-{
-    constexpr int CP = 64, MT = 2, NT = 2, BM = 256, RS = CP * 2 + 16;
-    constexpr int CHUNK = 8 * 1024;
-    const TripleJob &P = jobs.j[blockIdx.z];
-    const int K = P.K, nd = P.n_dil;
-    const int h2 = (K - 1) / 2;
-    int sumd = 0, dmax = 1;
-    for (int d = 0; d < nd; d++) { sumd += P.dil[d]; dmax = P.dil[d] > dmax ? P.dil[d] : dmax; }
-    const int H = h2 * (sumd + nd);
-    const int TM = BM - 2 * H;
-    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(blockIdx.x, tps * jobs.segs.nseg);
-    if (vt >= tps * jobs.segs.nseg) return;
-    const int useg = vt / tps;
-    const Seg sg = seg_at(jobs.segs, useg);
-    const int L = sg.rows * jobs.rate;
-    const int t0 = (vt - useg * tps) * TM;
-    if (t0 >= L) return;
-    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-    float *out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
-    const int XM = h2 * dmax;                         // zero margin of the operand region on either side of the tile
-    const int xrows = BM + 2 * XM + 2 * dmax;         // + slack: the last tap's look-ahead reads one tap past the end
-    const bool edge = t0 - H < 0 || t0 - H + BM > L;
-
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char *ring = smem + jobs.ring_off;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lg = lane >> 4;
-    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair16_kernel)
+    const char *abase = smem + (wave * 32 * MT + 2 * lc) * RS + lg * 16;      // block row 2c (+ lt), k group g (see resblock_pair_kernel)
     const char *bl = ring + lane * 16;
     const int nchunk = 2 * K * nd;                    // the block's weight stream: per pair conv1's taps, then conv2's
     // chunk g -> ring slot g & 3; base pointers of the (at most six) convs in scalar registers
@@ -2859,22 +2155,6 @@ hipError_t launch_block64(hipStream_t s, const TripleJob *jobs, int njobs, const
     js.ring_off = round_up(rows_max * (64 * 2 + 16), 1024);
     const size_t lds = (size_t)js.ring_off + 4 * 8192;
     if (lds > 80 * 1024) return hipErrorInvalidValue;
-    bool x16 = knob(ZV_PAIR16) != 0;          // the 16 x 16 x 32 form wherever its weight stream exists (same bits)
-    for (int i = 0; i < njobs; i++)
-        for (int d = 0; d < jobs[i].n_dil; d++) x16 = x16 && jobs[i].w1x[d] && jobs[i].w2x[d];
-    if (x16)
-    {
-        for (int i = 0; i < PAIR_MAX_JOBS; i++)
-            for (int d = 0; d < TRIPLE_MAX_DIL; d++)
-            {
-                js.j[i].w1[d] = js.j[i].w1x[d];
-                js.j[i].w2[d] = js.j[i].w2x[d];
-            }
-        hipError_t e = hipFuncSetAttribute((const void *)resblock_block64x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(resblock_block64x_kernel, dim3(round_up(gx, 8), 1, njobs), dim3(256), lds, s, js);
-        return hipGetLastError();
-    }
     hipError_t e = hipFuncSetAttribute((const void *)resblock_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(resblock_block64_kernel, dim3(round_up(gx, 8), 1, njobs), dim3(256), lds, s, js);
@@ -2907,19 +2187,14 @@ static hipError_t launch_pair_cfg(hipStream_t s, const PairJobs &js, int njobs, 
 #ifdef ZV_DIAG
     lds += (size_t)knob(ZV_LDS_PAD);       // diagnostic build: extra bytes of LDS per workgroup = a lower occupancy on purpose
 #endif
-    // the 16 x 16 x 32 form (same bits, a higher clock under load) wherever its weight copies exist; ZV_PAIR16 = 0: the 32 x 32 x 16 form
-    bool x16 = knob(ZV_PAIR16) != 0;
-    for (int i = 0; i < njobs; i++) x16 = x16 && js.j[i].w1x && js.j[i].w2x;
-    auto launch = [&](auto kern) {
-        if (lds > 64 * 1024)
-        {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
-        return hipGetLastError();
-    };
-    return x16 ? launch(resblock_pair16_kernel<CP, MT, MERGE>) : launch(resblock_pair_kernel<CP, MT, MERGE>);
+    auto kern = resblock_pair_kernel<CP, MT, MERGE>;
+    if (lds > 64 * 1024)
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, js);
+    return hipGetLastError();
 }
 
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out)
@@ -3182,45 +2457,6 @@ __device__ __forceinline__ void dma_weights32(const void *wsrc, char *wlds, int 
                                          (__attribute__((address_space(3))) void *)(wlds + blk * 1024), 16, 0, 0);
 }
 
-// one conv of the 32-channel block: K taps x 2 channel halves, A rows and B fragments from LDS, both two steps ahead of the
-// MFMAs that consume them (four register sets in rotation, a scheduling fence per step)
-template <int MT, bool SWAP>
-__device__ __forceinline__ void mfma32_ldsw(floatx16 (&acc)[MT][1], const char *ap, int dilRS, const char *wl, int K)
-{
-    constexpr int RS = 32 * 2 + 16;
-    half8 a[4][MT], b[4][1];
-#define ZV_LD(slot, aptr, woff)                                                                                       \
-    {                                                                                                                 \
-        const char *ap_ = (aptr);                                                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[slot][mt] = ZV_ABL_LD(a[slot], ap_, mt);                  \
-        b[slot][0] = *(const half8 *)(wl + (woff));                                                                   \
-    }
-#define ZV_ST(slot, Z)                                   \
-    mfma_step<MT, 1, SWAP, Z>(acc, a[slot], b[slot]);    \
-    __builtin_amdgcn_sched_barrier(0);
-    // step s = 2 * tap + channel half: fragments in slot s % 4, requested two steps ahead.  Tap 0 starts the accumulators from
-    // the constant 0; the other K - 1 taps (K odd: triple_supported) go two at a time.  Round 2 walked bodies of four taps,
-    // the last of them on zero weights: one tap in K + 1, 12.5 % of the stage's MFMAs.  The last iteration's two look-ahead
-    // requests read one tap past the end (operand rows and weight-buffer slack that exist) and are never used.
-    const char *t1 = ap + dilRS;
-    ZV_LD(0, ap, 0)
-    ZV_LD(1, ap + 32, 1024)
-    ZV_LD(2, t1, 2 * 1024) ZV_ST(0, true)
-    ZV_LD(3, t1 + 32, 3 * 1024) ZV_ST(1, false)
-    for (int it = (K - 1) >> 1; it > 0; it--)
-    {
-        const char *t2 = t1 + dilRS, *t3 = t2 + dilRS;
-        ZV_LD(0, t2, 4 * 1024) ZV_ST(2, false)
-        ZV_LD(1, t2 + 32, 5 * 1024) ZV_ST(3, false)
-        ZV_LD(2, t3, 6 * 1024) ZV_ST(0, false)
-        ZV_LD(3, t3 + 32, 7 * 1024) ZV_ST(1, false)
-        t1 = t3;
-        wl += 4 * 1024;
-    }
-#undef ZV_ST
-#undef ZV_LD
-}
-
 // (A variant with Y in the transposed accumulator layout — both convs with the weights as the A operand, 8-byte operand
 // writes, 16-byte tile loads / stores: half the vector instructions — measured 7 % SLOWER: a 16-byte access per lane in
 // that layout touches 32 rows x 32 bytes per instruction, against 2 rows x 128 bytes for the 4-byte column accesses.)
@@ -3232,243 +2468,7 @@ __device__ __forceinline__ void lds_st_b64(unsigned addr, uint2 v)
 {
     asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-template <int OFF>
-__device__ __forceinline__ void lds_st_b16(unsigned addr, _Float16 h)
-{
-    asm volatile("ds_write_b16 %0, %1 offset:%2" : : "v"(addr), "v"(h), "n"(OFF) : "memory");
-}
-
-// the operand writes of the whole-block kernel, unrolled at compile time (every LDS offset an immediate)
-template <int MT_, int I = 0>
-__device__ __forceinline__ void xwrite_all(unsigned xa, const float (&y)[MT_][16], float sl)
-{
-    constexpr int mt = I / 16, r = I % 16;
-    lds_st_b16<(mt * 32 + (r & 3) + 8 * (r >> 2)) * 80>(xa, (_Float16)lrelu_max(y[mt][r], sl));
-    if constexpr (I + 1 < MT_ * 16) xwrite_all<MT_, I + 1>(xa, y, sl);
-}
-template <int MT_, int I = 0>
-__device__ __forceinline__ void pack_all(unsigned pa, const uint2 (&pk)[MT_][4])
-{
-    constexpr int mt = I / 4, q = I % 4;
-    lds_st_b64<mt * 32 * 80 + 16 * q>(pa, pk[mt][q]);
-    if constexpr (I + 1 < MT_ * 4) pack_all<MT_, I + 1>(pa, pk);
-}
-
-template <int MT, int R>
-__global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32_kernel(const TripleJobs jobs)
-{
-    constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
-    constexpr int RS = CP * 2 + 16, NKC = CP / 16;
-    // workgroup -> (job, tile): with `il` jobs interleaved the MRF branches of one stretch of the sequence run next to each
-    // other on the same XCD (blockIdx.x & 7 picks the XCD), so only the first of them fetches the shared input from HBM.
-    const int il = jobs.interleave;
-    const int bx = il > 1 ? (int)(((blockIdx.x >> 3) / il) << 3 | (blockIdx.x & 7)) : (int)blockIdx.x;
-    const int jb = il > 1 ? (int)((blockIdx.x >> 3) % il) : (int)blockIdx.z;
-    const TripleJob &P = jobs.j[jb];
-    int H;
-    {
-        int sumd0 = 0;
-        for (int d = 0; d < P.n_dil; d++) sumd0 += P.dil[d];
-        H = ((P.K - 1) / 2) * (sumd0 + P.n_dil);
-    }
-    const int TM = R - 2 * H;
-    const int tps = (jobs.segs.max_rows * jobs.rate + TM - 1) / TM;
-    const int vt = zv_xcd_tile(bx, tps * jobs.segs.nseg);
-    if (vt >= tps * jobs.segs.nseg) return;
-    const int useg = vt / tps;
-    const Seg sg = seg_at(jobs.segs, useg);
-    const int L = sg.rows * jobs.rate;
-    const int t0 = (vt - useg * tps) * TM;
-    if (t0 >= L) return;
-    const bool edge = t0 - H < 0 || t0 - H + R > L;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31;
-    const int irow0 = wave * 32 * MT + 4 * (lane >> 5);   // tile row of register [mt][r]: irow0 + mt*32 + (r&3) + 8*(r>>2)
-#ifdef ZV_STAMPS
-    const int stamp_wg = blockIdx.x;
-    int stamp_k = 1;
-#endif
-    ZV_STAMP(0)
-
-    const int K = P.K, nd = P.n_dil;
-    const int h2 = (K - 1) / 2;
-    int dmax = 1;
-    for (int d = 0; d < nd; d++) dmax = P.dil[d] > dmax ? P.dil[d] : dmax;
-    const float *y_seg = P.y + (size_t)sg.row0 * jobs.rate * CP;
-    const int XM = h2 * dmax;
-    const int xrows = R + 2 * XM + 5 * dmax;          // + slack: zero-weight taps and the last A prefetch read past the margin
-    const int nb = ((K * NKC + 3) >> 2) >> 1;         // 8-step bodies per conv
-    const int nblk = 8 * nb;                          // weight fragments per conv (real ones first, zero blocks behind)
-
-    // Two weight buffers where they fit (jobs.db_mask: 3- and 7-tap branches): a conv's fragments are requested while the
-    // conv BEFORE it runs and have a whole MFMA loop plus a pack / epilogue phase to land.  With one buffer (11 taps) the
-    // request can only follow the barrier that ends the previous conv and the next barrier waits for it: phase stamps of
-    // that form show 2 us of DMA latency in each of a block's six pack / epilogue phases (27.6 us per workgroup).
-    // The biases of the block's six convs sit in LDS, so nothing in the loop below waits on the vector-memory counter but
-    // the barriers that are meant to.
-    const bool db = (jobs.db_mask >> jb) & 1;
-    char *wlds = smem + round_up(xrows * RS, 1024);
-    char *wlds2 = db ? wlds + nblk * 1024 : wlds;                  // conv2's weights
-    float *blds = (float *)(wlds + (db ? 2 : 1) * nblk * 1024 + 2048);      // behind the last-prefetch slack: [d][conv][32]
-    dma_weights32(P.w1[0], wlds, nblk, wave, lane, NWV);
-    if (tid < 64 * nd)
-    {
-        const int d_ = tid >> 6, c_ = tid & 31;
-        blds[tid] = (tid & 32) ? P.b2[d_][c_] : P.b1[d_][c_];
-    }
-    // the margins of the operand region stay zero for the whole kernel: rows [0, XM) and [XM + R, xrows)
-    {
-        const int lo = XM * RS / 16, hi0 = (XM + R) * RS / 16, hi = xrows * RS / 16;
-        for (int i = tid; i < lo; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
-        for (int i = hi0 + tid; i < hi; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
-    }
-    // tile row i <-> time t0 - H + i; rows outside [0, L) are out of the descriptor's range and read as 0
-    float yreg[MT][16];
-    {
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
-        const int voff = ((t0 - H + irow0) * CP + col) * 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                yreg[mt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, voff + (mt * 32 + (r & 3) + 8 * (r >> 2)) * CP * 4, 0, 0));
-    }
-
-    const char *abase = smem + (wave * 32 * MT + (lane & 31)) * RS + (lane >> 5) * 16;
-    const char *wl = wlds + lane * 16, *wl2 = wlds2 + lane * 16;
-    const float sl = P.slope;
-    for (int d = 0; d < nd; d++)
-    {
-        const int dil = P.dil[d], h1 = h2 * dil;
-        if (d)
-        {
-            // the previous conv2 is done reading XT and its weights (raw barrier: conv1's weights may be in flight)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (!db) dma_weights32(P.w1[d], wlds, nblk, wave, lane, NWV);
-        }
-        // ---- X = f16(lrelu(Y)) into region rows XM .. XM + R - 1
-        {
-            static_assert(RS == 80, "xwrite_all / pack_all carry the row stride");
-            xwrite_all<MT>((unsigned)(uintptr_t)(smem + (XM + irow0) * RS + col * 2), yreg, sl);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                       // X complete, conv1's weights landed (the barrier drains the DMA)
-        if (db) dma_weights32(P.w2[d], wlds2, nblk, wave, lane, NWV);      // under conv1 and the pack
-#ifdef ZV_STAMPS
-        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
-#endif
-
-        // ---- conv1 (dilated), transposed product; output tile row i reads region rows XM + i - h1 + tap*dil
-        floatx16 acc[MT][1];
-        if (ZV_DBGBITS(P.dbg) & 2)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[mt][0][r] = 0.f;
-        if (!(ZV_DBGBITS(P.dbg) & 2)) mfma32_ldsw<MT, true>(acc, abase + (XM - h1) * RS, dil * RS, wl, K);
-#ifdef ZV_STAMPS
-        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
-#endif
-        // every wave is done reading X and conv1's weights (raw barrier: conv2's weights may be in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // (the biases are read before any request goes out: hipcc orders an LDS read behind a pending LDS-DMA with vmcnt(0))
-        // (raw ds_reads: hipcc would order a visible LDS read behind the weight DMA in flight with vmcnt(0) and drain it here)
-        float4 bq[4];
-        float bias2;
-        {
-            const unsigned ba = (unsigned)(uintptr_t)(blds + d * 64 + 4 * (lane >> 5)), bb = (unsigned)(uintptr_t)(blds + d * 64 + 32 + col);
-            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:32\n\tds_read_b128 %2, %5 offset:64\n\t"
-                         "ds_read_b128 %3, %5 offset:96\n\tds_read_b32 %4, %6\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bias2)
-                         : "v"(ba), "v"(bb)
-                         : "memory");
-        }
-        if (!db) dma_weights32(P.w2[d], wlds, nblk, wave, lane, NWV);
-        // ---- xt = f16(lrelu(conv1 + b1)), zero outside [0, L)
-        {
-            const int hh = lane >> 5;
-            const unsigned pa = (unsigned)(uintptr_t)(smem + (XM + wave * 32 * MT + (lane & 31)) * RS + 4 * hh * 2);
-            uint2 pkv[MT][4];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-            {
-                const int i = wave * 32 * MT + mt * 32 + (lane & 31);
-                const int t = t0 - H + i;
-                const bool in = !edge || (t >= 0 && t < L);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                {
-                    uint2 pk = lrelu4_f16(acc[mt][0][4 * q + 0] + bq[q].x, acc[mt][0][4 * q + 1] + bq[q].y,
-                                          acc[mt][0][4 * q + 2] + bq[q].z, acc[mt][0][4 * q + 3] + bq[q].w, sl);
-                    if (edge)
-                    {
-                        pk.x = in ? pk.x : 0u;
-                        pk.y = in ? pk.y : 0u;
-                    }
-                    pkv[mt][q] = pk;
-                }
-            }
-            pack_all<MT>(pa, pkv);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                       // XT complete, conv2's weights landed
-        if (db && d + 1 < nd) dma_weights32(P.w1[d + 1], wlds, nblk, wave, lane, NWV);      // under conv2, the update and the next X write
-#ifdef ZV_STAMPS
-        if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
-#endif
-
-        // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
-        if (!(ZV_DBGBITS(P.dbg) & 2)) mfma32_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
-        {
-            const float bias = bias2;
-            if (edge)
-            {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                    {
-                        const int t = t0 - H + irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-                        const float v = (acc[mt][0][r] + bias) + yreg[mt][r];
-                        yreg[mt][r] = (t >= 0 && t < L) ? v : 0.f;
-                    }
-            }
-            else
-            {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) yreg[mt][r] = (acc[mt][0][r] + bias) + yreg[mt][r];
-            }
-        }
-    }
-
-    // ---- store the centre rows (tile rows H .. H + TM - 1, time < L): anything else gets an out-of-range offset
-    if (ZV_DBGBITS(P.dbg) & 4) return;
-    float *const out_seg = P.out + (size_t)sg.row0 * jobs.rate * CP;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)out_seg, 0, L * CP * 4, 0x00020000);
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const int i = irow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-            const int t = t0 - H + i;
-            const int voff = (i >= H && i < H + TM && t >= 0) ? (t * CP + col) * 4 : -4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yreg[mt][r]), rs_out, voff, 0, ZV_ST_AUX);
-        }
-#ifdef ZV_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ZV_STAMP(11)
-#endif
-}
-
-// ---- the whole-block kernel on v_mfma_f32_16x16x32_f16 (round 4; layouts as in resblock_pair16_kernel, same bits) ----
+// ---- the whole-block kernel on v_mfma_f32_16x16x32_f16 (round 4; layouts as in resblock_pair_kernel, same bits) ----
 // one conv of the 32-channel block: one step per tap (32 channels), operand rows (two 16-row tiles per 32-row block: rows 2c + lt)
 // and weight fragments (two 16-channel tiles) from LDS, one tap ahead of the MFMAs that consume them
 template <int MT, bool SWAP>
@@ -3528,7 +2528,7 @@ __device__ __forceinline__ void pack_all16(unsigned pa, const uint2 (&pk)[MT_][2
 }
 
 template <int MT, int R>
-__global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32x_kernel(const TripleJobs jobs)
+__global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resblock_block32_kernel(const TripleJobs jobs)
 {
     constexpr int CP = 32, NWV = R / 32 / MT, NTH = 64 * NWV;
     constexpr int RS = CP * 2 + 16, NKC = CP / 16;
@@ -3558,7 +2558,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 16 x 16 x 32 layouts (see resblock_pair16_kernel): lane (c, g); the f32 tile in conv2's accumulator layout
+    // 16 x 16 x 32 layouts (see resblock_pair_kernel): lane (c, g); the f32 tile in conv2's accumulator layout
     // y[mt][wt][lt][i] = tile row wave*32*MT + mt*32 + 8g + 2i + lt, channel 2c + wt
     const int lc = lane & 15, lg = lane >> 4;
     const int irow0 = wave * 32 * MT + 8 * lg;
@@ -3825,20 +2825,16 @@ hipError_t launch_triple(hipStream_t s, const TripleJob *jobs, int njobs, int n_
                 hipLaunchKernelGGL(kern, grid2, dim3(nth), lds2, s, js);
                 return hipGetLastError();
             };
-            // the 16 x 16 x 32 form wherever its weight copies exist (ZV_PAIR16 = 0: the 32 x 32 x 16 form; same bits)
-            bool x16 = knob(ZV_PAIR16) != 0;
+            // (the whole-block kernel of batches reads the 16 x 16 x 32 fragment order: TripleJob::w1x / w2x)
             for (int i = 0; i < njobs; i++)
-                for (int d = 0; d < jobs[i].n_dil; d++) x16 = x16 && jobs[i].w1x[d] && jobs[i].w2x[d];
-            if (x16)
-            {
-                for (int i = 0; i < PAIR_MAX_JOBS; i++)
-                    for (int d = 0; d < TRIPLE_MAX_DIL; d++)
-                    {
-                        js.j[i].w1[d] = js.j[i].w1x[d];
-                        js.j[i].w2[d] = js.j[i].w2x[d];
-                    }
-                return R == 512 ? launch(resblock_block32x_kernel<2, 512>, 512) : launch(resblock_block32x_kernel<2, 256>, 256);
-            }
+                for (int d = 0; d < jobs[i].n_dil; d++)
+                    if (!jobs[i].w1x[d] || !jobs[i].w2x[d]) return hipErrorInvalidValue;
+            for (int i = 0; i < PAIR_MAX_JOBS; i++)
+                for (int d = 0; d < TRIPLE_MAX_DIL; d++)
+                {
+                    js.j[i].w1[d] = js.j[i].w1x[d];
+                    js.j[i].w2[d] = js.j[i].w2x[d];
+                }
             return R == 512 ? launch(resblock_block32_kernel<2, 512>, 512) : launch(resblock_block32_kernel<2, 256>, 256);
         }
     }
@@ -3897,36 +2893,6 @@ size_t conv_gemm_weight_halfs(int Cin_p, int Cout_p, int K)
     return (size_t)conv_gemm_tiles(Cout_p) * conv_gemm_units(Cin_p, K) * 2048;      // 4 fragments of 512 halfs per (unit, tile)
 }
 
-void pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst)
-{
-    const int ng = conv_gemm_groups(Cout_p), nu = conv_gemm_units(Cin_p, K), ntk = conv_gemm_tiles(Cout_p);
-    size_t gbase = 0;                                // halfs before group g
-    for (int g = 0; g < ng; g++)
-    {
-        const int ntg = (g == ng - 1) ? ntk - 8 * g : 8;          // 8, or 9 in the last group
-        int u = 0;
-        for (int c0 = 0; c0 < Cin_p; c0 += 256)
-        {
-            const int nsub = (std::min(256, Cin_p - c0) + 63) / 64;
-            for (int tap = 0; tap < K; tap++)
-                for (int sub = 0; sub < nsub; sub++, u++)
-                    for (int st = 0; st < 4; st++)
-                        for (int nt = 0; nt < ntg; nt++)
-                        {
-                            uint16_t *d = dst + gbase + (((size_t)u * 4 + st) * ntg + nt) * 512;
-                            for (int lane = 0; lane < 64; lane++)
-                                for (int j = 0; j < 8; j++)
-                                {
-                                    const int oc = (g * 8 + nt) * 32 + (lane & 31);
-                                    const int ic = c0 + sub * 64 + st * 16 + 8 * (lane >> 5) + j;
-                                    d[lane * 8 + j] = (oc < OC && ic < IC) ? w[((size_t)oc * IC + ic) * K + tap] : (uint16_t)0;
-                                }
-                        }
-        }
-        gbase += (size_t)nu * 4 * ntg * 512;
-    }
-}
-
 // one 1-KiB piece global -> LDS: lane i lands at lds_base + 16 * i.  The DMA is invisible to hipcc (which would answer a
 // visible one with vmcnt(0) in front of every LDS read): the kernel counts it by hand.  M0 carries the LDS address and is
 // restored (cdna_hip_programming.md §5.7); s_nop 4: the descriptor / M0 may have been written by the instructions just before.
@@ -3951,306 +2917,18 @@ __device__ __forceinline__ u32x4s make_rsrc(const void *base, unsigned bytes)
     return r;
 }
 
-// EXTRA: the last group's workgroups, which also own the conv's ninth leftover tile (one more 32 x 32 tile per wave).  Two
+// ---- the kernel runs on v_mfma_f32_16x16x32_f16 (round 4; round 3: 32x32x16): one half unit = ONE step of 32 channels — the
+// same chain per output element as two k16 steps (scripts/mfma_shape_bits.hip) —, 8 x 4 tiles of 16 x 16 per wave.
+// EXTRA: the last group's workgroups, which also own the conv's ninth leftover tile (one more 32 x 32 block per wave).  Two
 // instantiations behind one launch: the 8-tile path keeps its own schedule and registers.
-template <bool EXTRA>
-__device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g, const int rt)
-{
-    // The K loop runs in HALF units (32 channels = two k16 steps: a 256-row x 64-byte operand slice + the 2 x ntg weight
-    // fragments) through a ring of four LDS slots: half h is consumed while h + 1 and h + 2 are in flight and h + 3 is being
-    // requested (the first form — whole units, two buffers, one unit ahead — ran at the DMA's latency: 64 KiB requested and
-    // waited for per 1.1 us of MFMAs took 2.1 us).  One barrier per half unit; the waits are counted (vmcnt(8) leaves two
-    // halves in flight), never 0 inside the loop.
-    constexpr int BM = 256, UNIT = 32768;            // bytes of an 8-tile unit's weight block
-    constexpr int ntg = EXTRA ? 9 : 8;
-    constexpr int AH = 16384, BH = ntg * 2048;       // bytes of a half unit's operand slice / weight fragments
-    constexpr int SLOT = AH + 18432;                 // one ring slot (room for 9 tiles)
-    const ConvJob &J = jobs.j[0];
-    const int useg = rt / jobs.tps;
-    const Seg sg = seg_at(jobs.segs, useg);
-    const int L = sg.rows * jobs.rate;
-    const int m0 = (rt - useg * jobs.tps) * BM;
-    if (m0 >= L) return;
-    const size_t row0 = (size_t)sg.row0 * jobs.rate;
-
-    extern __shared__ __attribute__((aligned(1024))) char smem[];     // [4 slots][A 16 KiB | B 16 (18) KiB]
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int K = J.K, dil = J.dil, Cin_p = J.Cin_p, ldx = J.ldx;
-    const int nunits = conv_gemm_units_dev(Cin_p, K), nhalf = 2 * nunits;
-    constexpr int bunit = ntg * 4096;                // bytes of one unit's weight block
-
-    // descriptors: the utterance's rows of the operand tensor (anything outside reads as zero = the conv's zero padding) and
-    // this group's weight stream (groups before the last one have 8 tiles)
-    // (ZV_DBGBITS(J.dbg), timing ablations only: bit 1 / bit 2 = the operand / weight descriptor covers nothing, every piece arrives as zeros
-    // without touching memory)
-    const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (ZV_DBGBITS(J.dbg) & 1) ? 0u : (unsigned)((size_t)L * ldx * 2));
-    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (ZV_DBGBITS(J.dbg) & 2) ? 0u : (unsigned)((size_t)nunits * bunit));
-
-    // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
-    // slot); the slot holds the 16-byte piece (slot ^ ((row >> 2) & 3)) of the row's 64 bytes
-    int a_voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-    {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
-        const int piece = (lane & 3) ^ ((row >> 2) & 3);
-        a_voff[i] = ((m0 - J.pad + row) * ldx + piece * 8) * 2;
-    }
-
-    // half-unit walk: (chunk, tap, 64-channel block of the chunk, half)
-    int uc0 = 0, utap = 0, usub = 0, unsub = (min(256, Cin_p) + 63) >> 6, uh = 0;
-    unsigned i_abase = 0;
-    int i_aoff = 0, i_boff = 0;
-    auto issue_begin = [&](int h) {
-        i_abase = lds0 + (h & 3) * SLOT;
-        i_aoff = (utap * dil * ldx + uc0 + usub * 64 + uh * 32) * 2;
-        i_boff = (h >> 1) * bunit + (h & 1) * BH;
-        if (++uh == 2)
-        {
-            uh = 0;
-            if (++usub == unsub)
-            {
-                usub = 0;
-                if (++utap == K)
-                {
-                    utap = 0;
-                    uc0 += 256;
-                    unsub = (min(256, Cin_p - uc0) + 63) >> 6;
-                }
-            }
-        }
-    };
-    // per half and wave: two operand pieces, two weight fragments (+ one more for waves 0 and 1 where a ninth tile rides along:
-    // 18 fragments); the same count in every half, so the counted waits below hold
-    const bool no_dma = (ZV_DBGBITS(J.dbg) & 4) != 0;          // timing ablation: no piece is requested at all (the loop runs on stale LDS)
-    auto issue_pa = [&](int i) {
-        if (!no_dma) dma_piece(rs_a, i_abase + (wave * 2 + i) * 1024, (unsigned)(a_voff[i] + i_aoff));
-    };
-    auto issue_pb = [&](int i) {
-        if (!no_dma) dma_piece(rs_b, i_abase + AH + (wave * 2 + i) * 1024, (unsigned)(i_boff + (wave * 2 + i) * 1024 + lane * 16));
-    };
-    auto issue_part = [&](int i) {
-        issue_pa(i);
-        issue_pb(i);
-    };
-    auto issue_x = [&]() {
-        if (EXTRA && wave < 2 && !no_dma) dma_piece(rs_b, i_abase + AH + (16 + wave) * 1024, (unsigned)(i_boff + (16 + wave) * 1024 + lane * 16));
-    };
-    const bool five = EXTRA && wave < 2;             // this wave requests five pieces per half
-
-    // fragment addresses inside a slot: A (mt, step): row wm*128 + mt*32 + (lane & 31), piece 2*step + (lane >> 5), swizzled;
-    // B (nt, step): fragment step*ntg + wn*2 + nt
-    const int swz = ((lane & 31) >> 2) & 3, hh = lane >> 5;
-    int a_rd[2], ax_rd[2];
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-    {
-        a_rd[st] = (wm * 128 + (lane & 31)) * 64 + (((2 * st + hh) ^ swz) << 4);
-        ax_rd[st] = (wave * 32 + (lane & 31)) * 64 + (((2 * st + hh) ^ swz) << 4);      // the ninth tile: rows wave * 32 ...
-    }
-    const int b_rd = AH + wn * 2048 + lane * 16;
-    constexpr int b_st = ntg * 1024;
-
-    floatx16 acc[4][2];
-    floatx16 accx;
-#pragma unroll
-    for (int r = 0; r < 16; r++) accx[r] = 0.f;
-    // waves 4-7 (the second-dispatched half of the workgroup) lose the issue arbitration to their SIMD partners 0-3 on every
-    // segment (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for them
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    // prologue: halves 0, 1, 2 requested
-#pragma unroll
-    for (int h = 0; h < 3; h++)
-        if (h < nhalf)
-        {
-            issue_begin(h);
-            issue_part(0);
-            issue_part(1);
-            issue_x();
-        }
-#ifdef ZV_STAMPS
-    // diagnostic build: wave 0 splits its loop time into (counted wait, barrier, the rest) and stores the sums
-    unsigned long long st_wait = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_loop0 = st_t0;
-#endif
-    // step-0 fragments of the half about to be consumed: read from LDS at the END of the previous iteration (that half has
-    // landed for every wave one barrier earlier: the counted wait below asks for half h + 1, not h), so the MFMAs start right
-    // behind the barrier instead of an LDS round trip later (the two waves of a SIMD stand at the barrier together: nothing
-    // else would fill that gap — 250 of a half unit's 1 900 cycles)
-    half8 a0[4], b0[2], ax0, bx0;
-#define ZV_G_READ0(hn)                                                                                            \
-    {                                                                                                             \
-        const char *nb_ = smem + ((hn) & 3) * SLOT;                                                               \
-        _Pragma("unroll") for (int mt = 0; mt < 4; mt++) a0[mt] = *(const half8 *)(nb_ + a_rd[0] + mt * 2048);    \
-        _Pragma("unroll") for (int nt = 0; nt < 2; nt++) b0[nt] = *(const half8 *)(nb_ + b_rd + nt * 1024);       \
-        if constexpr (EXTRA)                                                                                      \
-        {                                                                                                         \
-            ax0 = *(const half8 *)(nb_ + ax_rd[0]);                                                               \
-            bx0 = *(const half8 *)(nb_ + AH + 8 * 1024 + lane * 16);                                              \
-        }                                                                                                         \
-    }
-    {
-        // half 0 (and 1) landed and visible before the loop starts
-        if (nhalf > 2)
-        {
-            if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        ZV_G_READ0(0)
-    }
-    for (int h = 0; h < nhalf; h++)
-    {
-#ifdef ZV_STAMPS
-        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
-#endif
-        // before the barrier: half h + 1 has landed for this wave (at most the pieces of h + 2 outstanding); after it, for every
-        // wave, and every wave is done reading slot (h - 1) & 3 = (h + 3) & 3: half h + 3 can go there
-        if (h > 0)
-        {
-            if (h + 2 < nhalf)
-            {
-                if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            }
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef ZV_STAMPS
-            const unsigned long long st_b = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();
-#ifdef ZV_STAMPS
-            const unsigned long long st_c = __builtin_amdgcn_s_memtime();
-            st_wait += st_b - st_a;
-            st_bar += st_c - st_b;
-#endif
-        }
-        const bool more = h + 3 < nhalf;
-        if (more) issue_begin(h + 3);
-        const char *buf = smem + (h & 3) * SLOT;
-        half8 a1[4], b1[2], ax1, bx1;
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) a1[mt] = *(const half8 *)(buf + a_rd[1] + mt * 2048);
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) b1[nt] = *(const half8 *)(buf + b_rd + b_st + nt * 1024);
-        if constexpr (EXTRA)
-        {
-            ax1 = *(const half8 *)(buf + ax_rd[1]);
-            bx1 = *(const half8 *)(buf + AH + b_st + 8 * 1024 + lane * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // four groups of four MFMAs (one output-tile column of one k16 step), one piece requested behind each
-#define ZV_G_COL(av, bv, nt, ZERO)                                                                                       \
-    _Pragma("unroll") for (int mt = 0; mt < 4; mt++)                                                                     \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[mt], bv[nt], (ZERO) ? zero16 : acc[mt][nt], 0, 0, 0);    \
-    __builtin_amdgcn_sched_barrier(0);
-        const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h == 0)
-        {
-            ZV_G_COL(a0, b0, 0, true)
-            if (more) issue_pa(0);
-            __builtin_amdgcn_sched_barrier(0);
-            ZV_G_COL(a0, b0, 1, true)
-        }
-        else
-        {
-            ZV_G_COL(a0, b0, 0, false)
-            if (more) issue_pa(0);
-            __builtin_amdgcn_sched_barrier(0);
-            ZV_G_COL(a0, b0, 1, false)
-        }
-        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax0, bx0, accx, 0, 0, 0);
-        if (more) issue_pb(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the next half's first fragments (visible since this iteration's barrier), under the last eight MFMAs
-        if (h + 1 < nhalf) ZV_G_READ0(h + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        ZV_G_COL(a1, b1, 0, false)
-        if (more) issue_pa(1);
-        __builtin_amdgcn_sched_barrier(0);
-        ZV_G_COL(a1, b1, 1, false)
-        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax1, bx1, accx, 0, 0, 0);
-        if (more)
-        {
-            issue_pb(1);
-            issue_x();
-        }
-#undef ZV_G_COL
-    }
-#undef ZV_G_READ0
-#ifdef ZV_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 4096)
-    {
-        const unsigned long long st_e = __builtin_amdgcn_s_memtime();
-        unsigned long long *sb = zv_stamp_buf + (size_t)blockIdx.x * ZV_STAMP_N;
-        sb[0] = st_e - st_loop0;      // loop cycles
-        sb[1] = st_wait;              // in the counted vmcnt waits
-        sb[2] = st_bar;               // in the barriers
-        sb[3] = nhalf;
-        sb[4] = EXTRA;
-        sb[7] = 1;
-    }
-#endif
-    constexpr bool extra = EXTRA;
-
-    // ---- epilogue: bias, residual, scale, activation, f32 store, InstanceNorm partial sums (as conv1d_mfma_kernel) ----
-    const int Cout_p = J.Cout_p;
-    const float escale = J.escale;
-    const bool has_res = J.res != nullptr;
-    const float *res = has_res ? J.res + row0 * J.ldres : nullptr;
-    float *out = (float *)J.out + row0 * J.ldo;
-    auto finish_tile = [&](const floatx16 &tile, int t_first, int oc, int blk) {
-        if (oc >= Cout_p) return;
-        const float bias = J.bias ? J.bias[oc] : 0.f;
-        float resv[16];
-        if (has_res)
-        {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const int t = t_first + (r & 3) + 8 * (r >> 2);
-                resv[r] = res[(size_t)(t < L ? t : L - 1) * J.ldres + oc];
-            }
-        }
-        float outv[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-        {
-            const int t = t_first + (r & 3) + 8 * (r >> 2);
-            float v = tile[r] + bias;
-            if (has_res) v = v + resv[r];
-            v = v * escale;
-            if (J.eact) v = lrelu(v, J.oslope);
-            outv[r] = v;
-            if (t < L) __builtin_nontemporal_store(v, out + (size_t)t * J.ldo + oc);
-        }
-        if (J.stat_part && oc < J.stat_C && blk * 32 < L)
-            tile_stats_store(outv, t_first, L, J.stat_part + (((size_t)useg * J.stat_nblk + blk) * J.stat_C + oc) * 2);
-    };
-    const int tbase = m0 + wm * 128 + 4 * (lane >> 5);
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-            finish_tile(acc[mt][nt], tbase + mt * 32, ((g * 8 + wn * 2 + nt) << 5) + (lane & 31), (m0 >> 5) + wm * 4 + mt);
-    if (extra) finish_tile(accx, m0 + wave * 32 + 4 * (lane >> 5), ((g * 8 + 8) << 5) + (lane & 31), (m0 >> 5) + wave);
-}
-
-
-// ---- conv_gemm_kernel on v_mfma_f32_16x16x32_f16 (round 4): one half unit = ONE step of 32 channels (same chain per output
-// element as the two k16 steps above: scripts/mfma_shape_bits.hip), 8 x 4 tiles of 16 x 16 per wave.
 //   * operand image: row r's four 16-byte pieces at slots piece ^ ((r >> 1) & 3) — the swizzle under which the 16 x 16 x 32 A
 //     fragment reads (lane = row c of a 16-row tile, k group g = piece) fall on 16 distinct slots per lane group;
-//   * weights (pack_conv_weight_gemm16): per half unit [tile32][wt][lane][8 halfs], column c of tile wt = channel 2c + wt: a lane's
+//   * weights (pack_conv_weight_gemm): per half unit [tile32][wt][lane][8 halfs], column c of tile wt = channel 2c + wt: a lane's
 //     two tiles of a 32-channel group are NEIGHBOURING channels, the epilogue moves 8 bytes per lane (four rows x 128 bytes per
 //     instruction: half the instructions of the 4-byte form);
 //   * the InstanceNorm partial sums keep tile_stats_store's summation order (rows 0-3, 8-11, 16-19, 24-27 then the other half,
 //     each a sequential f64 chain): the chain is handed from lane group to lane group.
-void pack_conv_weight_gemm16(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst)
+void pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst)
 {
     const int ng = conv_gemm_groups(Cout_p), nu = conv_gemm_units(Cin_p, K), ntk = conv_gemm_tiles(Cout_p);
     size_t gbase = 0;                                // halfs before group g
@@ -4282,7 +2960,7 @@ void pack_conv_weight_gemm16(const uint16_t *w, int K, int IC, int OC, int Cin_p
 }
 
 template <bool EXTRA>
-__device__ __forceinline__ void conv_gemm16_body(const ConvJobs &jobs, const int g, const int rt)
+__device__ __forceinline__ void conv_gemm_body(const ConvJobs &jobs, const int g, const int rt)
 {
     constexpr int BM = 256, UNIT = 32768;            // bytes of an 8-tile unit's weight block
     constexpr int ntg = EXTRA ? 9 : 8;
@@ -4307,7 +2985,7 @@ __device__ __forceinline__ void conv_gemm16_body(const ConvJobs &jobs, const int
     constexpr int bunit = ntg * 4096;                // bytes of one unit's weight block
 
     const u32x4s rs_a = make_rsrc((const _Float16 *)J.x0 + row0 * ldx, (unsigned)((size_t)L * ldx * 2));
-    const u32x4s rs_b = make_rsrc((const char *)J.w8x + (size_t)g * nunits * UNIT, (unsigned)((size_t)nunits * bunit));
+    const u32x4s rs_b = make_rsrc((const char *)J.w8 + (size_t)g * nunits * UNIT, (unsigned)((size_t)nunits * bunit));
 
     // this wave's two operand pieces of a half unit: piece j = wave * 2 + i covers tile rows 16 j .. 16 j + 15; lane -> (row,
     // slot); the slot holds the 16-byte piece (slot ^ ((row >> 1) & 3)) of the row's 64 bytes
@@ -4604,40 +3282,6 @@ __device__ __forceinline__ void conv_gemm16_body(const ConvJobs &jobs, const int
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvJobs jobs)
 {
     const ConvJob &J = jobs.j[0];
-    // workgroup -> (group of 8 output tiles, row tile)
-    const int ng = (gemm_groups_dev(J.Cout_p));
-    const int rts = jobs.tps * jobs.segs.nseg;
-    int g, rt;
-    if (jobs.order == 1 && (ng == 1 || ng == 2 || ng == 4))
-    {
-        // XCD-aware: one group per XCD (its weight stream stays in that L2).  Measured: no faster than the plain order.
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / ng;
-        g = xcd % ng;
-        rt = idx * per + xcd / ng;
-    }
-    else if (jobs.order == 2 && ng > 1)
-    {
-        // longest jobs first: the last group may carry a ninth tile (+ 12 % work); dispatched first, its workgroups are paired
-        // with 8-tile ones on their CUs by the dispatcher (two workgroups per CU and launch: 9 + 8 instead of 9 + 9)
-        if ((int)blockIdx.x < rts) { g = ng - 1; rt = blockIdx.x; }
-        else { const int b2 = blockIdx.x - rts; g = b2 % (ng - 1); rt = b2 / (ng - 1); }
-    }
-    else
-    {
-        g = blockIdx.x % ng;
-        rt = blockIdx.x / ng;
-    }
-    if (rt >= rts) return;
-    const bool ninth = g == ng - 1 && ((J.Cout_p + 31) >> 5) - 8 * ng == 1;
-    if (ninth)
-        conv_gemm_body<true>(jobs, g, rt);
-    else
-        conv_gemm_body<false>(jobs, g, rt);
-}
-
-__global__ __launch_bounds__(512, 2) void conv_gemm16_kernel(const ConvJobs jobs)
-{
-    const ConvJob &J = jobs.j[0];
     const int ng = (gemm_groups_dev(J.Cout_p));
     const int rts = jobs.tps * jobs.segs.nseg;
     int g, rt;
@@ -4655,9 +3299,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm16_kernel(const ConvJobs jobs
     if (rt >= rts) return;
     const bool ninth = g == ng - 1 && ((J.Cout_p + 31) >> 5) - 8 * ng == 1;
     if (ninth)
-        conv_gemm16_body<true>(jobs, g, rt);
+        conv_gemm_body<true>(jobs, g, rt);
     else
-        conv_gemm16_body<false>(jobs, g, rt);
+        conv_gemm_body<false>(jobs, g, rt);
 }
 
 static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs &segs, int rate)
@@ -4680,13 +3324,6 @@ static hipError_t launch_conv_gemm(hipStream_t s, const ConvJob &job, const Segs
     // (per launch, like every other launcher here: the attribute is stored per device)
     hipError_t e = hipFuncSetAttribute((const void *)conv_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    if (knob(ZV_PAIR16) != 0 && job.w8x && js.order != 1)
-    {   // the 16 x 16 x 32 form (same bits; ZV_PAIR16 = 0: the 32 x 32 x 16 form)
-        e = hipFuncSetAttribute((const void *)conv_gemm16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(conv_gemm16_kernel, grid, dim3(512), lds, s, js);
-        return hipGetLastError();
-    }
     hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(512), lds, s, js);
     return hipGetLastError();
 }

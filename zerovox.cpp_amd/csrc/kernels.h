@@ -102,8 +102,7 @@ struct ConvJob
     int          ck;             // input-channel chunk staged per LDS pass (set at pack time)
     // weights packed in MFMA-fragment order (see pack_conv_weight), bias padded to 32*ntiles
     const void  *w;
-    const void  *w8;             // the same weights in conv_gemm_kernel's stream order (pack_conv_weight_gemm), or null
-    const void  *w8x;            // ... in conv_gemm16_kernel's (pack_conv_weight_gemm16: 16 x 16 x 32 fragments), or null
+    const void  *w8;             // the same weights in conv_gemm_kernel's stream order (pack_conv_weight_gemm: 16 x 16 x 32 fragments), or null
     const float *bias;
     // epilogue: v = acc + bias; v += res; v *= escale; v = lrelu(v, oslope) if eact; store f32 | f16
     const float *res;
@@ -151,7 +150,6 @@ int    conv_gemm_tiles(int Cout_p);         // output tiles conv_gemm_kernel cov
 int    conv_gemm_units(int Cin_p, int K);
 size_t conv_gemm_weight_halfs(int Cin_p, int Cout_p, int K);
 void   pack_conv_weight_gemm(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst);
-void   pack_conv_weight_gemm16(const uint16_t *w, int K, int IC, int OC, int Cin_p, int Cout_p, uint16_t *dst);
 // all jobs of one launch share the segments, Cout_p and the tile configuration; job.L is ignored (rows come from segs)
 hipError_t launch_conv(hipStream_t s, const ConvJob *jobs, int njobs, int n_cu, const Segs &segs, int rate);
 
@@ -163,10 +161,8 @@ struct PairJob
 {
     const float *y;          // [L][Cp] f32
     float       *out;        // [L][Cp] f32, must not alias y (neighbour workgroups read y's halo)
-    const void  *w1, *w2;    // packed by pack_pair_weight (zero-padded per-tile segments)
-    const void  *w1r, *w2r;  // packed by pack_pair_weight_ring ([tap][kc][ntile] fragments), or null
-    const void  *w1rx, *w2rx; // packed by pack_pair_weight_ring16 for resblock_pair64x_kernel, or null
-    const void  *w1x, *w2x;  // packed by pack_pair_weight16 (conv1: A-operand form, conv2: B-operand form) for resblock_pair16_kernel, or null
+    const void  *w1, *w2;    // packed by pack_pair_weight16 (16 x 16 x 32 fragments; conv1: A-operand form, conv2: B-operand form)
+    const void  *w1r, *w2r;  // the same as the stream resblock_pair64_kernel moves through its LDS ring (pack_pair_weight_ring), or null
     const float *b1, *b2;
     int          L, Cp, K, dil;
     float        slope;
@@ -194,13 +190,13 @@ bool       pair_supported(int Cp, int K);
 size_t     pair_weight_halfs(int Cp, int K);
 // GGUF conv weight (ggml ne [K, C, C], f16) -> fused-kernel layout
 void       pack_pair_weight(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
-// the same weight in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair16_kernel); conv2_layout: the conv's second layer
+// the same weight in v_mfma_f32_16x16x32_f16 fragment order (resblock_pair_kernel, resblock_block32_kernel); conv2_layout: the
+// pair's second conv (B-operand form: column c of tile wt = channel 2c + wt), else the first (A-operand form: row r = channel 16 wt + r)
 size_t     pair_weight16_halfs(int Cp, int K);
 void       pack_pair_weight16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout);
-// the same weight as the stream resblock_pair64_kernel moves through its LDS ring: [tap][kc][ntile][lane][8 halfs]
+// the same weight as the stream resblock_pair64_kernel / resblock_block64_kernel move through their LDS ring: [tap][step of 32 channels][ntile][wt][lane][8 halfs]
 size_t     pair_ring_weight_halfs(int Cp, int K);
-void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst);
-void       pack_pair_weight_ring16(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout);
+void       pack_pair_weight_ring(const uint16_t *w, int K, int C, int Cp, uint16_t *dst, bool conv2_layout);
 // merge_out (may be null): the jobs share every time tile and only the sum of their outputs, (out_0 + out_1) + out_2, is
 // stored there (the MRF sum of a stage's last dilation pair); the jobs' own `out` pointers are then unused
 hipError_t launch_pair(hipStream_t s, const PairJob *jobs, int njobs, int n_cu, const Segs &segs, int rate, float *merge_out = nullptr);
@@ -213,9 +209,9 @@ struct TripleJob
 {
     const float *y;                       // [L][Cp] f32 block input (may be shared by several jobs)
     float       *out;                     // [L][Cp] f32 block output, must not alias y
-    const void  *w1[TRIPLE_MAX_DIL], *w2[TRIPLE_MAX_DIL];    // pack_pair_weight layout
-    // the same weights in 16 x 16 x 32 fragment order, or null: launch_block64 — the ring stream (pack_pair_weight_ring16);
-    // launch_triple — pack_pair_weight16 (conv1 A-operand form, conv2 B-operand form)
+    // launch_triple: w1 / w2 in pack_pair_weight layout (resblock_triple_kernel: 32 x 32 x 16 fragments) and w1x / w2x in
+    // pack_pair_weight16 layout (resblock_block32_kernel); launch_block64: w1 / w2 the ring stream (pack_pair_weight_ring)
+    const void  *w1[TRIPLE_MAX_DIL], *w2[TRIPLE_MAX_DIL];
     const void  *w1x[TRIPLE_MAX_DIL], *w2x[TRIPLE_MAX_DIL];
     const float *b1[TRIPLE_MAX_DIL], *b2[TRIPLE_MAX_DIL];
     int          dil[TRIPLE_MAX_DIL];

@@ -27,9 +27,8 @@ namespace zv
     X(ZV_CONV_GEMM, 1)         /* 0 never, 1 batches, 2 always: conv_gemm_kernel for wide convs over an f16 operand tensor */         \
     X(ZV_CONV_STREAM, 1)       /* 0 never, 1 batches, 2 always: memory-bound 3-tap convs (the last upsample convs) on conv_stream_kernel */ \
     X(ZV_UP_GEMM, 1)           /* 0 never, 1 batches, 2 always: the wide upsample convs behind an f16 operand pass on conv_gemm_kernel */ \
-    X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 1 one group per XCD, 2 the 9-tile group first */ \
+    X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 2 the 9-tile group first */ \
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
-    X(ZV_PAIR16, 1)            /* 0: the fused pair kernel on v_mfma_f32_32x32x16_f16 instead of 16x16x32 (same bits) */              \
     X(ZV_BLOCK64, 3)           /* 64-channel stage of a batch: branches with at most that many taps run their first two dilation pairs in one launch (resblock_block64_kernel); 0 never, negative: at any length */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
     X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always, 3 always on 512-row tiles: whole-block kernel with its weights in LDS */                      \

@@ -68,9 +68,6 @@ ConvW Model::load_conv(const GgufFile &g, const std::string &wname, const std::s
         pack_conv_weight_gemm((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, p8.data());
         c.w8 = dev_alloc(p8.size() * 2);
         ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
-        pack_conv_weight_gemm16((const uint16_t *)w.data, c.K, c.Cin, c.Cout, c.Cin_p, c.Cout_p, p8.data());
-        c.w8x = dev_alloc(p8.size() * 2);
-        ZV_HIP(hipMemcpy(c.w8x, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
     }
     if (!bname.empty())
     {
@@ -146,9 +143,6 @@ ConvW Model::load_upsample(const GgufFile &g, int idx, int stride, int expect_ci
         pack_conv_weight_gemm(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, p8.data());
         c.w8 = dev_alloc(p8.size() * 2);
         ZV_HIP(hipMemcpy(c.w8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
-        pack_conv_weight_gemm16(v.data(), c.K, IC, c.Cout, c.Cin_p, c.Cout_p, p8.data());
-        c.w8x = dev_alloc(p8.size() * 2);
-        ZV_HIP(hipMemcpy(c.w8x, p8.data(), p8.size() * 2, hipMemcpyHostToDevice));
     }
     snprintf(nm, sizeof(nm), "_meldec.upsamples.%d.1.b", idx);
     const GgufTensor &b = g.get(nm);
@@ -274,7 +268,7 @@ Model::Model(const std::string &path, int dev) : device(dev)
                         pack_pair_weight((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, pk.data());
                         *dst[q] = dev_alloc(pk.size() * 2 + 8192);
                         ZV_HIP(hipMemcpy(*dst[q], pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
-                        {   // the same weights in 16 x 16 x 32 fragment order (resblock_pair16_kernel): conv1 as the A operand, conv2 as B
+                        {   // the same weights in 16 x 16 x 32 fragment order (resblock_pair_kernel, resblock_block32_kernel): conv1 as the A operand, conv2 as B
                             std::vector<uint16_t> xk(pair_weight16_halfs(rp.c1.Cout_p, rp.c1.K));
                             pack_pair_weight16((const uint16_t *)g.get(nm).data, rp.c1.K, C, rp.c1.Cout_p, xk.data(), q == 1);
                             void **xd = q ? &rp.x2 : &rp.x1;
@@ -284,14 +278,10 @@ Model::Model(const std::string &path, int dev) : device(dev)
                         if (rp.c1.Cout_p == 64)
                         {
                             std::vector<uint16_t> rk(pair_ring_weight_halfs(64, rp.c1.K));
-                            pack_pair_weight_ring((const uint16_t *)g.get(nm).data, rp.c1.K, C, 64, rk.data());
+                            pack_pair_weight_ring((const uint16_t *)g.get(nm).data, rp.c1.K, C, 64, rk.data(), q == 1);
                             void **rd = q ? &rp.r2 : &rp.r1;
                             *rd = dev_alloc(rk.size() * 2);
                             ZV_HIP(hipMemcpy(*rd, rk.data(), rk.size() * 2, hipMemcpyHostToDevice));
-                            pack_pair_weight_ring16((const uint16_t *)g.get(nm).data, rp.c1.K, C, 64, rk.data(), q == 1);
-                            void **rxd = q ? &rp.rx2 : &rp.rx1;
-                            *rxd = dev_alloc(rk.size() * 2);
-                            ZV_HIP(hipMemcpy(*rxd, rk.data(), rk.size() * 2, hipMemcpyHostToDevice));
                         }
                     }
                 }
@@ -784,7 +774,6 @@ ConvJob Model::job(const ConvW &w) const
     j.ck = w.ck;
     j.w = w.w;
     j.w8 = w.w8;
-    j.w8x = w.w8x;
     j.bias = w.bias;
     j.pro = PRO_ACT;
     j.slope = 1.0f;
@@ -1058,8 +1047,6 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                     {
                         t.w1[d] = rp[d].r1;
                         t.w2[d] = rp[d].r2;
-                        t.w1x[d] = rp[d].rx1;
-                        t.w2x[d] = rp[d].rx2;
                         t.b1[d] = rp[d].c1.bias;
                         t.b2[d] = rp[d].c2.bias;
                         t.dil[d] = voc_.dil[d];
@@ -1109,14 +1096,10 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
                 memset(&p, 0, sizeof(p));
                 p.y = yin;
                 p.out = yout;
-                p.w1 = rp.p1;
-                p.w2 = rp.p2;
+                p.w1 = rp.x1;
+                p.w2 = rp.x2;
                 p.w1r = rp.r1;
                 p.w2r = rp.r2;
-                p.w1x = rp.x1;
-                p.w2x = rp.x2;
-                p.w1rx = rp.rx1;
-                p.w2rx = rp.rx2;
                 p.b1 = rp.c1.bias;
                 p.b2 = rp.c2.bias;
                 p.Cp = Cp;

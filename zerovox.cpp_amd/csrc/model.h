@@ -22,7 +22,6 @@ struct ConvW
 {
     void  *w = nullptr;
     void  *w8 = nullptr;        // conv_gemm_kernel's stream order (wide decoder convs), or null
-    void  *w8x = nullptr;       // conv_gemm16_kernel's (16 x 16 x 32 fragments), or null
     float *bias = nullptr;
     int    K = 0, Cin = 0, Cout = 0, Cin_p = 0, Cout_p = 0, ck = 0;
 };
@@ -196,7 +195,8 @@ class Model
     ConvW  load_conv(const GgufFile &g, const std::string &wname, const std::string &bname, int expect_cin = -1, bool gemm_pack = false);
     ConvW  load_upsample(const GgufFile &g, int idx, int stride, int expect_cin);
 
-    struct ResPair { ConvW c1, c2; void *p1 = nullptr, *p2 = nullptr, *r1 = nullptr, *r2 = nullptr, *x1 = nullptr, *x2 = nullptr, *rx1 = nullptr, *rx2 = nullptr; };   // p1/p2: fused-kernel weight layout, r1/r2: LDS-ring layout (64 channels)
+    // p1/p2: 32 x 32 x 16 fragment order (resblock_triple_kernel), x1/x2: 16 x 16 x 32 order (pair kernel, block32), r1/r2: LDS-ring stream (64 channels)
+    struct ResPair { ConvW c1, c2; void *p1 = nullptr, *p2 = nullptr, *r1 = nullptr, *r2 = nullptr, *x1 = nullptr, *x2 = nullptr; };
     struct Voc
     {
         float *mean = nullptr, *scale = nullptr;
