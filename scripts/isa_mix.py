@@ -1,33 +1,35 @@
-#!/usr/bin/env python3
-"""static instruction mix per kernel from `hipcc -S --cuda-device-only` output: isa_mix.py file.s [name-substring ...]"""
+"""Static instruction mix per kernel of a hipcc -S listing (diagnostic): python scripts/isa_mix.py conv.s [name-substring]
+   -> per kernel: instructions by class (mfma / valu / salu / lds / vmem / waitcnt+barrier / branch), and per basic block with MFMAs."""
 import re, sys, collections
-lines = open(sys.argv[1]).read().split('\n')
-pats = sys.argv[2:]
-cur, funcs = None, collections.OrderedDict()
-for ln in lines:
-    m = re.match(r'^(_ZN2zv\S+):', ln)
+src = open(sys.argv[1]).read().split("\n")
+pat = sys.argv[2] if len(sys.argv) > 2 else ""
+blocks = len(sys.argv) > 3
+def cls(op):
+    if op.startswith("v_mfma"): return "mfma"
+    if op.startswith("v_accvgpr"): return "acc_mov"
+    if op.startswith("v_"): return "valu"
+    if op.startswith("s_waitcnt") or op.startswith("s_barrier") or op.startswith("s_nop") or op.startswith("s_setprio") or op.startswith("s_sleep"): return "wait"
+    if op.startswith("s_cbranch") or op.startswith("s_branch"): return "branch"
+    if op.startswith("s_"): return "salu"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith("buffer_") or op.startswith("global_") or op.startswith("flat_") or op.startswith("scratch_"): return "vmem"
+    return "other"
+name = None; cnt = None; bb = None; bbs = None
+def flush():
+    if name and pat in name and cnt:
+        import subprocess
+        print(name[:150]); print("   ", dict(cnt))
+        if blocks:
+            for lbl, c in bbs:
+                if c.get("mfma", 0) >= 4 or c.get("valu", 0) >= 16: print("      %-14s %s" % (lbl, dict(c)))
+for ln in src:
+    m = re.match(r"^(_Z\w+):", ln)
     if m:
-        cur = m.group(1); funcs[cur] = []
-        continue
-    if ln.startswith('.Lfunc_end'):
-        cur = None
-    if cur: funcs[cur].append(ln.strip())
-for name, body in funcs.items():
-    if pats and not any(p in name for p in pats): continue
-    cnt = collections.Counter()
-    for line in body:
-        if not line or line.startswith(('.', ';')) or line.endswith(':'): continue
-        op = line.split()[0]
-        if op.startswith('v_mfma'): cnt['mfma'] += 1
-        elif op.startswith('v_accvgpr'): cnt['accvgpr'] += 1
-        elif op.startswith('v_'): cnt['valu'] += 1; cnt['v:' + op] += 1
-        elif op.startswith('s_waitcnt'): cnt['waitcnt'] += 1
-        elif op.startswith('s_barrier'): cnt['barrier'] += 1
-        elif op.startswith('s_nop'): cnt['nop'] += 1
-        elif op.startswith('s_'): cnt['salu'] += 1
-        elif op.startswith('ds_'): cnt['lds'] += 1; cnt['d:' + op] += 1
-        elif op.startswith(('buffer_', 'global_', 'flat_')): cnt['vmem'] += 1
-    print(name)
-    print('  ', {k: v for k, v in cnt.items() if ':' not in k})
-    print('  ', sorted([(v, k[2:]) for k, v in cnt.items() if k.startswith('v:')], reverse=True)[:16])
-    print('  ', sorted([(v, k[2:]) for k, v in cnt.items() if k.startswith('d:')], reverse=True)[:6])
+        flush(); name = m.group(1); cnt = collections.Counter(); bbs = []; bb = collections.Counter(); bbs.append(("entry", bb)); continue
+    if name is None: continue
+    m = re.match(r"^(\.LBB\w+):", ln)
+    if m: bb = collections.Counter(); bbs.append((m.group(1), bb)); continue
+    m = re.match(r"^\s+([a-z_0-9]+)\s", ln + " ")
+    if m and not ln.strip().startswith("."):
+        c = cls(m.group(1)); cnt[c] += 1; bb[c] += 1
+    if ln.startswith(".Lfunc_end"): flush(); name = None

@@ -21,14 +21,20 @@ buf = np.zeros(NW * NS, np.uint64)
 lib = C.CDLL(capi.LIB_PATH)
 lib.zv_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.zv_debug_read_stamps(buf.ctypes.data, buf.size) == 0
-s = buf.reshape(NW, NS)
-s = s[s[:, 11] > 0].astype(np.int64)
-print("workgroups stamped:", len(s))
-s[:, 10] = s[:, 9]              # slot 10 is not stamped (three dilation pairs)
-t = (s - s[:, 0:1]) * 10.0
+S = buf.reshape(NW, NS)
 names = ["load + X write 0", "conv1 0", "pack 0", "conv2+update+X write 1", "conv1 1", "pack 1", "conv2+update+X write 2", "conv1 2", "pack 2", "-", "conv2 2 + store + drain"]
-d = np.diff(t, axis=1)
-for i, n in enumerate(names):
-    if n == "-": continue
-    print(f"  {n:26s} mean {d[:, i].mean():8.0f} ns  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
-print("  total                      mean %8.0f ns" % t[:, 11].mean())
+wg = np.arange(NW)
+# the batch launch interleaves the three MRF branches (3, 7, 11 taps) over the workgroup index: job = (blockIdx.x >> 3) % 3
+for jb, taps in ((None, "all"), (0, 3), (1, 7), (2, 11)):
+    sel = S[:, 11] > 0
+    if jb is not None: sel &= ((wg >> 3) % 3) == jb
+    s = S[sel].astype(np.int64)
+    print(f"branch {taps}: workgroups stamped: {len(s)}")
+    if not len(s): continue
+    s[:, 10] = s[:, 9]              # slot 10 is not stamped (three dilation pairs)
+    t = (s - s[:, 0:1]) * 10.0
+    d = np.diff(t, axis=1)
+    for i, n in enumerate(names):
+        if n == "-": continue
+        print(f"  {n:26s} mean {d[:, i].mean():8.0f} ns  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+    print("  total                      mean %8.0f ns" % t[:, 11].mean())

@@ -2509,15 +2509,21 @@ __device__ __forceinline__ void lds_st_b32(unsigned addr, unsigned v)
     asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 // the operand writes (two neighbouring channels per lane and row: 4-byte stores) and the xt pack, unrolled at compile time
+// (y[mt][wt][lt] holds four rows of one channel: the slope multiply goes two rows at a time, v_pk_mul_f32)
 template <int MT_, int I = 0>
-__device__ __forceinline__ void xwrite_all16(unsigned xa, const float (&y)[MT_][2][2][4], float sl)
+__device__ __forceinline__ void xwrite_all16(unsigned xa, const floatx4 (&y)[MT_][2][2], float sl)
 {
-    constexpr int mt = I / 8, lt = (I / 4) % 2, i = I % 4;
-    half2v h;
-    h[0] = (_Float16)lrelu_max(y[mt][0][lt][i], sl);
-    h[1] = (_Float16)lrelu_max(y[mt][1][lt][i], sl);
-    lds_st_b32<(mt * 32 + 2 * i + lt) * 80>(xa, *(const unsigned *)&h);
-    if constexpr (I + 1 < MT_ * 8) xwrite_all16<MT_, I + 1>(xa, y, sl);
+    constexpr int mt = I / 2, lt = I % 2;
+    const floatx4 s0 = y[mt][0][lt] * sl, s1 = y[mt][1][lt] * sl;
+#define ZV_XW(i)                                                                                                  \
+    {                                                                                                             \
+        const float2v r = {lrelu_max_pre(y[mt][0][lt][i], s0[i]), lrelu_max_pre(y[mt][1][lt][i], s1[i])};      \
+        const half2v h = __builtin_convertvector(r, half2v);                                                     \
+        lds_st_b32<(mt * 32 + 2 * i + lt) * 80>(xa, *(const unsigned *)&h);                                       \
+    }
+    ZV_XW(0) ZV_XW(1) ZV_XW(2) ZV_XW(3)
+#undef ZV_XW
+    if constexpr (I + 1 < MT_ * 2) xwrite_all16<MT_, I + 1>(xa, y, sl);
 }
 template <int MT_, int I = 0>
 __device__ __forceinline__ void pack_all16(unsigned pa, const uint2 (&pk)[MT_][2][2])
@@ -2602,7 +2608,7 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
         for (int i = hi0 + tid; i < hi; i += NTH) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
     }
     // tile row i <-> time t0 - H + i; rows outside [0, L) are out of the descriptor's range and read as 0
-    float yreg[MT][2][2][4];
+    floatx4 yreg[MT][2][2];          // [mt][wt][lt][i]
     {
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)y_seg, 0, L * CP * 4, 0x00020000);
         const int voff = ((t0 - H + irow0) * CP + 2 * lc) * 4;
@@ -2675,22 +2681,30 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #pragma unroll
                 for (int lt = 0; lt < 2; lt++)
                 {
-                    const int i = wave * 32 * MT + mt * 32 + 2 * lc + lt;
-                    const int t = t0 - H + i;
-                    const bool in = !edge || (t >= 0 && t < L);
 #pragma unroll
                     for (int wt = 0; wt < 2; wt++)
-                    {
-                        uint2 pk = lrelu4_f16(acc[mt][0][wt][lt][0] + bq[wt].x, acc[mt][0][wt][lt][1] + bq[wt].y,
-                                              acc[mt][0][wt][lt][2] + bq[wt].z, acc[mt][0][wt][lt][3] + bq[wt].w, sl);
-                        if (edge)
-                        {
-                            pk.x = in ? pk.x : 0u;
-                            pk.y = in ? pk.y : 0u;
-                        }
-                        pkv[mt][lt][wt] = pk;
-                    }
+                        pkv[mt][lt][wt] = lrelu4_f16(acc[mt][0][wt][lt][0] + bq[wt].x, acc[mt][0][wt][lt][1] + bq[wt].y,
+                                                     acc[mt][0][wt][lt][2] + bq[wt].z, acc[mt][0][wt][lt][3] + bq[wt].w, sl);
                 }
+            if (edge)
+            {
+                // (a branch the compiler keeps: interior tiles skip the selects)
+                asm volatile("; edge tile: rows outside [0, L) are zero");
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+                    {
+                        const int t = t0 - H + wave * 32 * MT + mt * 32 + 2 * lc + lt;
+                        const bool in = t >= 0 && t < L;
+#pragma unroll
+                        for (int wt = 0; wt < 2; wt++)
+                        {
+                            pkv[mt][lt][wt].x = in ? pkv[mt][lt][wt].x : 0u;
+                            pkv[mt][lt][wt].y = in ? pkv[mt][lt][wt].y : 0u;
+                        }
+                    }
+            }
             pack_all16<MT>(pa, pkv);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -2703,24 +2717,29 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
         // ---- conv2 (dil 1): output tile row i reads region rows XM + i - h2 + tap;  Y = Y + (conv2 + b2), 0 outside [0, L)
         mfma32x_ldsw<MT, false>(acc, abase + (XM - h2) * RS, RS, wl2, K);
         {
+            // (four rows of a channel per accumulator: packed adds, v_pk_add_f32, two rows at a time)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int lt = 0; lt < 2; lt++)
+                for (int wt = 0; wt < 2; wt++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                    {
-                        const float v0 = (acc[mt][0][0][lt][i] + bias2[0]) + yreg[mt][0][lt][i];
-                        const float v1 = (acc[mt][0][1][lt][i] + bias2[1]) + yreg[mt][1][lt][i];
-                        bool in = true;
-                        if (edge)
+                    for (int lt = 0; lt < 2; lt++) yreg[mt][wt][lt] = (acc[mt][0][wt][lt] + bias2[wt]) + yreg[mt][wt][lt];
+            if (edge)
+            {
+                asm volatile("; edge tile: rows outside [0, L) are zero");
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int lt = 0; lt < 2; lt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
                         {
                             const int t = t0 - H + irow0 + mt * 32 + 2 * i + lt;
-                            in = t >= 0 && t < L;
+                            const bool in = t >= 0 && t < L;
+                            yreg[mt][0][lt][i] = in ? yreg[mt][0][lt][i] : 0.f;
+                            yreg[mt][1][lt][i] = in ? yreg[mt][1][lt][i] : 0.f;
                         }
-                        yreg[mt][0][lt][i] = in ? v0 : 0.f;
-                        yreg[mt][1][lt][i] = in ? v1 : 0.f;
-                    }
+            }
         }
     }
 
@@ -2734,9 +2753,9 @@ __global__ __launch_bounds__(64 * (R / 32 / MT), (MT >= 4 ? 2 : 4)) void resbloc
 #pragma unroll
             for (int i = 0; i < 4; i++)
             {
-                const int row = irow0 + mt * 32 + 2 * i + lt;
-                const int t = t0 - H + row;
-                const int voff = (row >= H && row < H + TM && t >= 0) ? (t * CP + 2 * lc) * 4 : -8;
+                // (row >= H gives t = t0 + row - H >= 0; t < L is the descriptor's range)
+                const int ro = irow0 - H + mt * 32 + 2 * i + lt;
+                const int voff = (unsigned)ro < (unsigned)TM ? ((t0 + ro) * CP + 2 * lc) * 4 : -8;
                 const u32x2 o = {__float_as_uint(yreg[mt][0][lt][i]), __float_as_uint(yreg[mt][1][lt][i])};
                 __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, voff, 0, ZV_ST_AUX);
             }
