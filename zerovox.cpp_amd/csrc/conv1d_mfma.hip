@@ -38,16 +38,21 @@ static constexpr int CK_MAX = 256;
 #ifndef ZV_ST_AUX
 #define ZV_ST_AUX 2       // measured on the batch: -1.1 % (256 / 128 channels), -3.5 % (64), -1.3 % (32) against the default policy
 #endif
-// 16-byte pieces a thread keeps in flight while it stages a tile (10 — one round trip for every small tile — measured no
-// faster on the batch's upsample convs and costs the MT = 1 kernels a wave of occupancy)
-#ifndef ZV_STAGE_U
 // timing-only ablation build (-DZV_ABL_A): only the first row tile's A fragment is read from LDS, the others copy it
 #ifdef ZV_ABL_A
 #define ZV_ABL_LD(arr, p, mt) ((mt) == 0 ? *(const half8 *)(p) : arr[0])
 #else
 #define ZV_ABL_LD(arr, p, mt) (*(const half8 *)((p) + (mt) * 32 * RS))
 #endif
+// 16-byte pieces a thread keeps in flight while it stages a tile (10 — one round trip for every small tile — measured no
+// faster on the batch's upsample convs and costs the MT = 1 kernels a wave of occupancy)
+#ifndef ZV_STAGE_U
 #define ZV_STAGE_U 4
+#endif
+// ... in the single-utterance form of the generic kernel (one workgroup per CU at most: occupancy is not the price there): the
+// 34-row x 256-channel f32 tile of a chunk in one round trip instead of three
+#ifndef ZV_STAGE_US
+#define ZV_STAGE_US 9
 #endif
 #ifndef ZV_STAGE_U128
 #define ZV_STAGE_U128 12
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void con
             else
                 // (the big wave tiles have the registers — dead before the accumulators live — for 8 pieces in flight: a
                 // 64-row x 256-channel f32 tile in three round trips instead of five)
-                stage_tile<(MT * NT >= 4 && !SINGLE ? 8 : ZV_STAGE_U)>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
+                stage_tile<(SINGLE ? ZV_STAGE_US : (MT * NT >= 4 ? 8 : ZV_STAGE_U))>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         }
         __syncthreads();
 #ifdef ZV_STAMPS
