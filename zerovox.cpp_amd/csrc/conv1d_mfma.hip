@@ -817,6 +817,14 @@ __global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void con
                 {
                     // non-temporal stores: a conv's output is read by the NEXT launch, long after it has left the caches
                     // (measured on the batch: -1 ... -6.5 % per conv kernel, nothing slower)
+                    // ... single-utterance launches store plainly: their small outputs are still in the memory-side cache when the next
+                    // launch stages them (configs[2]: 1.711 -> 1.693 ms over three interleaved rounds)
+                    if constexpr (SINGLE)
+                    {
+                        if (J.out_f16) ((_Float16 *)J.out)[out0 + (size_t)t * J.ldo + oc] = (_Float16)v;
+                        else ((float *)J.out)[out0 + (size_t)t * J.ldo + oc] = v;
+                    }
+                    else
                     if (J.out_f16)
                         __builtin_nontemporal_store((_Float16)v, (_Float16 *)J.out + out0 + (size_t)t * J.ldo + oc);
                     else
@@ -1085,6 +1093,7 @@ static hipError_t launch_conv_from(hipStream_t s, const ConvJob *jobs, int njobs
     const int ntiles = (Cout_p + 31) / 32 - nt_begin;
     if (ntiles < 1) return hipErrorInvalidValue;
     // three output tiles already take four waves (one idles): the input tile is staged once instead of twice
+    // (two row tiles x two output tiles per workgroup instead, so that row pairs share weight fragments: a single utterance 1.71 -> 1.79 ms)
     const int WN = ntiles >= 3 ? 4 : (ntiles >= 2 ? 2 : 1);
     // pick the tallest wave tile (most B-fragment reuse) that still gives every CU about two workgroups; the tile
     // shape never changes an output bit: every output element is one accumulator chain over (chunk, tap, channel)
