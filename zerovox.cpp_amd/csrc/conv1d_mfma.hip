@@ -54,6 +54,15 @@ static constexpr int CK_MAX = 256;
 #ifndef ZV_STAGE_US
 #define ZV_STAGE_US 9
 #endif
+// ... and its loader waves (see conv1d_mfma_kernel): waves that only stage — chunk c + 1 into the second LDS tile while the four
+// MFMA waves walk chunk c.  They have their own vector-memory counters: the MFMA waves' counted waits on the weight stream never
+// queue behind a tile's loads.  0 = the round-3 form (every wave stages, then every wave multiplies).
+#ifndef ZV_SINGLE_LW
+#define ZV_SINGLE_LW 4
+#endif
+#ifndef ZV_STAGE_ULW
+#define ZV_STAGE_ULW 10
+#endif
 #ifndef ZV_STAGE_U128
 #define ZV_STAGE_U128 12
 #endif
@@ -128,6 +137,26 @@ __device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int 
     constexpr int pro = PRO;
     int r = tid / cols, c4 = tid - r * cols;
     const int dr = NTH / cols, dc = NTH - dr * cols;
+    // cols divides NTH (every 256- / 128- / 64- / 32- / 16-channel chunk): all of a thread's pieces are one column group, its
+    // per-channel vectors are loaded once (9 pieces x 4 vectors were 36 more loads per thread and chunk)
+    const bool hoist = dc == 0;
+    float4 hp0 = {0, 0, 0, 0}, hp1 = hp0, hp2 = hp0, hp3 = hp0;
+    if (hoist)
+    {
+        const int c = c0 + c4 * 4;
+        if constexpr (pro == PRO_NORM_ACT)
+        {
+            hp0 = *(const float4 *)(J.pstat + 2 * c);
+            hp1 = *(const float4 *)(J.pstat + 2 * c + 4);
+            hp2 = *(const float4 *)(J.pa + c);
+            hp3 = *(const float4 *)(J.pb + c);
+        }
+        else if constexpr (pro == PRO_MELNORM)
+        {
+            hp2 = *(const float4 *)(J.pa + c);
+            hp3 = *(const float4 *)(J.pb + c);
+        }
+    }
     for (int base = tid; base < total; base += NTH * U)
     {
         float4 v[U], v1[U], v2[U];
@@ -189,10 +218,14 @@ __device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int 
                     }
                     else if constexpr (pro == PRO_NORM_ACT)
                     {
-                        const float4 st0 = *(const float4 *)(J.pstat + 2 * c);       // mean,rstd,mean,rstd
-                        const float4 st1 = *(const float4 *)(J.pstat + 2 * c + 4);
-                        const float4 g = *(const float4 *)(J.pa + c);
-                        const float4 b = *(const float4 *)(J.pb + c);
+                        float4 st0 = hp0, st1 = hp1, g = hp2, b = hp3;               // st: mean,rstd,mean,rstd
+                        if (!hoist)
+                        {
+                            st0 = *(const float4 *)(J.pstat + 2 * c);
+                            st1 = *(const float4 *)(J.pstat + 2 * c + 4);
+                            g = *(const float4 *)(J.pa + c);
+                            b = *(const float4 *)(J.pb + c);
+                        }
                         x.x = ((x.x - st0.x) * st0.y) * g.x + b.x;
                         x.y = ((x.y - st0.z) * st0.w) * g.y + b.y;
                         x.z = ((x.z - st1.x) * st1.y) * g.z + b.z;
@@ -200,8 +233,12 @@ __device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int 
                     }
                     else if constexpr (pro == PRO_MELNORM)
                     {
-                        const float4 a = *(const float4 *)(J.pa + c);
-                        const float4 b = *(const float4 *)(J.pb + c);
+                        float4 a = hp2, b = hp3;
+                        if (!hoist)
+                        {
+                            a = *(const float4 *)(J.pa + c);
+                            b = *(const float4 *)(J.pb + c);
+                        }
                         x.x = (x.x - a.x) / b.x;
                         x.y = (x.y - a.y) / b.y;
                         x.z = (x.z - a.z) / b.z;
@@ -225,6 +262,152 @@ __device__ __forceinline__ void stage_tile_p(const StageSrc &J, char *smem, int 
         }
     }
 }
+
+// The same fill in two halves for the loader waves of the single-utterance kernel: stage_load_p requests a whole tile (at most
+// NTH * U pieces) into registers, stage_store_p applies the prologue and writes LDS — a barrier may sit between the two.  Same
+// operations per element as stage_tile_p.
+template <int U>
+struct StageRegs
+{
+    float4 v[U];
+    float4 p0, p1, p2, p3;      // the thread's per-channel vectors (when all its pieces are one column group)
+};
+template <int U, int PRO, int NTH>
+__device__ __forceinline__ void stage_load_p(const StageSrc &J, int c0, int ck, int row_t0, int rows, int tid, StageRegs<U> &R)
+{
+    const int cols = ck >> 2, total = rows * cols, L = J.L;
+    int r = tid / cols, c4 = tid - r * cols;
+    const int dr = NTH / cols, dc = NTH - dr * cols;
+    if (dc == 0)
+    {
+        const int c = c0 + c4 * 4;
+        if constexpr (PRO == PRO_NORM_ACT)
+        {
+            R.p0 = *(const float4 *)(J.pstat + 2 * c);
+            R.p1 = *(const float4 *)(J.pstat + 2 * c + 4);
+        }
+        if constexpr (PRO == PRO_NORM_ACT || PRO == PRO_MELNORM)
+        {
+            R.p2 = *(const float4 *)(J.pa + c);
+            R.p3 = *(const float4 *)(J.pb + c);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+    {
+        const int t = row_t0 + r;
+        const bool inr = tid + u * NTH < total && t >= 0 && t < L;
+        const size_t off = (size_t)(inr ? t : 0) * J.ldx + c0 + c4 * 4;
+        if constexpr (PRO == PRO_RAW_F16)
+        {
+            const uint2 h = *(const uint2 *)((const _Float16 *)J.x0 + off);
+            R.v[u].x = __uint_as_float(h.x);
+            R.v[u].y = __uint_as_float(h.y);
+        }
+        else
+            R.v[u] = *(const float4 *)((const float *)J.x0 + off);
+        r += dr;
+        c4 += dc;
+        if (c4 >= cols) { c4 -= cols; r++; }
+    }
+}
+template <int U, int PRO, int NTH>
+__device__ __forceinline__ void stage_store_p(const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid,
+                                              const StageRegs<U> &R)
+{
+    const int cols = ck >> 2, total = rows * cols, L = J.L;
+    int r = tid / cols, c4 = tid - r * cols;
+    const int dr = NTH / cols, dc = NTH - dr * cols;
+    const bool hoist = dc == 0;
+    const float4 hp0 = R.p0, hp1 = R.p1, hp2 = R.p2, hp3 = R.p3;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+    {
+        const int t = row_t0 + r;
+        const bool live = tid + u * NTH < total;
+        const bool inr = live && t >= 0 && t < L;
+        const int lofs = r * RS + c4 * 8;
+        if (live)
+        {
+            half4 h = {0, 0, 0, 0};
+            if (inr)
+            {
+                if constexpr (PRO == PRO_RAW_F16)
+                {
+                    const uint2 q = {__float_as_uint(R.v[u].x), __float_as_uint(R.v[u].y)};
+                    h = *(const half4 *)&q;
+                }
+                else
+                {
+                    float4 x = R.v[u];
+                    const int c = c0 + c4 * 4;
+                    (void)c;
+                    if constexpr (PRO == PRO_SCALE_ACT)
+                    {
+                        const float sc = J.pscale;
+                        x.x = x.x * sc;
+                        x.y = x.y * sc;
+                        x.z = x.z * sc;
+                        x.w = x.w * sc;
+                    }
+                    else if constexpr (PRO == PRO_NORM_ACT)
+                    {
+                        float4 st0 = hp0, st1 = hp1, g = hp2, b = hp3;               // st: mean,rstd,mean,rstd
+                        if (!hoist)
+                        {
+                            st0 = *(const float4 *)(J.pstat + 2 * c);
+                            st1 = *(const float4 *)(J.pstat + 2 * c + 4);
+                            g = *(const float4 *)(J.pa + c);
+                            b = *(const float4 *)(J.pb + c);
+                        }
+                        x.x = ((x.x - st0.x) * st0.y) * g.x + b.x;
+                        x.y = ((x.y - st0.z) * st0.w) * g.y + b.y;
+                        x.z = ((x.z - st1.x) * st1.y) * g.z + b.z;
+                        x.w = ((x.w - st1.z) * st1.w) * g.w + b.w;
+                    }
+                    else if constexpr (PRO == PRO_MELNORM)
+                    {
+                        float4 a = hp2, b = hp3;
+                        if (!hoist)
+                        {
+                            a = *(const float4 *)(J.pa + c);
+                            b = *(const float4 *)(J.pb + c);
+                        }
+                        x.x = (x.x - a.x) / b.x;
+                        x.y = (x.y - a.y) / b.y;
+                        x.z = (x.z - a.z) / b.z;
+                        x.w = (x.w - a.w) / b.w;
+                    }
+                    if constexpr (PRO != PRO_MELNORM)
+                    {
+                        const float sl = J.slope;
+                        x.x = lrelu(x.x, sl);
+                        x.y = lrelu(x.y, sl);
+                        x.z = lrelu(x.z, sl);
+                        x.w = lrelu(x.w, sl);
+                    }
+                    h[0] = (_Float16)x.x;
+                    h[1] = (_Float16)x.y;
+                    h[2] = (_Float16)x.z;
+                    h[3] = (_Float16)x.w;
+                }
+            }
+            *(half4 *)(smem + lofs) = h;
+        }
+        r += dr;
+        c4 += dc;
+        if (c4 >= cols) { c4 -= cols; r++; }
+    }
+}
+#define ZV_STAGE_SPLIT_SWITCH(pro, CALL)                       \
+    switch (pro)                                               \
+    {                                                          \
+        case PRO_RAW_F16: CALL(PRO_RAW_F16); break;            \
+        case PRO_ACT: CALL(PRO_ACT); break;                    \
+        case PRO_NORM_ACT: CALL(PRO_NORM_ACT); break;          \
+        case PRO_MELNORM: CALL(PRO_MELNORM); break;            \
+        default: CALL(PRO_SCALE_ACT); break;                   \
+    }
 
 template <int U, int NTH = 256>
 __device__ __forceinline__ void stage_tile(int pro, const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows,
@@ -646,9 +829,10 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 // (Measured dead end, round 3: two extra "loader" waves staging chunk c + 1 into a second LDS tile under the MFMA loop of chunk c:
 // decoder convs 311 -> 378 us; removed in round 4.)
 template <int MT, int WN, int NT, bool SINGLE = false>
-__global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
+__global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
     constexpr int WM = 4 / WN;
+    constexpr int LW = SINGLE ? ZV_SINGLE_LW : 0;          // loader waves (waves 4 .. 4 + LW - 1)
     constexpr int BM = 32 * MT * WM;
     const ConvJob &J = jobs.j[blockIdx.z];
 
@@ -709,18 +893,68 @@ __global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void con
     // SINGLE: the weight ring of the full 256-channel chunks, requested before the first tile is staged
     half8 bring[SINGLE ? 16 : 1];
     const bool single256 = SINGLE && NT == 1 && J.ck == 256 && Cin_p >= 256 && n_ok;
-    if constexpr (SINGLE)
-        if (single256) preload_ring16<MT>(bring, (const half8 *)J.w + (size_t)ntl * K * nicb * 64 + lane);
 #ifdef ZV_STAMPS
     const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.y;
     int stamp_k = 1;
 #endif
     ZV_STAMP(0)
+    // Loader waves: tile c is staged into LDS tile c & 1; barrier #c = "tile c is staged and the MFMA loop of chunk c - 1 is done", so
+    // the loaders fill tile c + 1 (last read by chunk c - 1) while the MFMA waves walk chunk c.  One barrier per chunk for every wave.
+    if constexpr (LW > 0)
+        if (wave >= 4)
+        {
+            constexpr int NL = 64 * (LW > 0 ? LW : 1), UL = ZV_STAGE_ULW;
+            const int ltid = tid - 256;
+            // a tile that fits the loaders' registers (and is one tensor) travels in two halves: tile c + 1 is REQUESTED before
+            // barrier #c — while the MFMA waves are still in chunk c - 1 — and written after it; the loaders' raw barrier does not
+            // wait for the vector-memory counter
+            const bool split = J.pro != PRO_SUM3_ACT && rows * (J.ck >> 2) <= NL * UL && !(ZV_DBGBITS(J.dbg) & 1);
+            StageRegs<UL> R;
+            const int ck0 = Cin_p < J.ck ? Cin_p : J.ck;
+#define ZV_LOAD_(P) stage_load_p<UL, P, NL>(S, cn_, ckn_, m0 - J.pad, rows, ltid, R)
+#define ZV_STORE_(P) stage_store_p<UL, P, NL>(S, dst_, RS, cn_, ckn_, m0 - J.pad, rows, ltid, R)
+            if (split)
+            {
+                const int cn_ = 0, ckn_ = ck0;
+                char *dst_ = smem;
+                ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_LOAD_)
+                ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_STORE_)
+            }
+            int par = 0;
+            for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
+            {
+                const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
+                const int cn_ = c0 + J.ck, ckn_ = (Cin_p - cn_ < J.ck) ? (Cin_p - cn_) : J.ck;
+                char *dst_ = smem + (par ^ 1) * jobs.tile_bytes;
+                if (!split)
+                {
+                    if (!(ZV_DBGBITS(J.dbg) & 1))
+                        stage_tile<ZV_STAGE_ULW, NL>(J.pro, S, smem + par * jobs.tile_bytes, RS, c0, ck, m0 - J.pad, rows, ltid);
+                    __syncthreads();
+                }
+                else
+                {
+                    if (cn_ < Cin_p) { ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_LOAD_) }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's writes of tile c have landed
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (cn_ < Cin_p) { ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_STORE_) }
+                }
+                par ^= 1;
+            }
+#undef ZV_LOAD_
+#undef ZV_STORE_
+            return;
+        }
+    // (behind the loaders' branch: the ring's registers and the loaders' never live side by side)
+    if constexpr (SINGLE)
+        if (single256) preload_ring16<MT>(bring, (const half8 *)J.w + (size_t)ntl * K * nicb * 64 + lane);
+    int par = 0;
     for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
     {
         const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-        if (c0) __syncthreads();
-        if (!(ZV_DBGBITS(J.dbg) & 1))
+        if (LW == 0 && c0) __syncthreads();
+        if (LW == 0 && !(ZV_DBGBITS(J.dbg) & 1))
         {
             // an f16 operand tensor (the decoder's pre-pass output) in 16-byte pieces, a 64-row x 256-channel tile in ONE round
             // trip (9 pieces per thread in flight); the 8-byte pieces of stage_tile took four (phase stamps: 5.5-6.2 us per chunk)
@@ -731,12 +965,21 @@ __global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void con
                 // 64-row x 256-channel f32 tile in three round trips instead of five)
                 stage_tile<(SINGLE ? ZV_STAGE_US : (MT * NT >= 4 ? 8 : ZV_STAGE_U))>(J.pro, S, smem, RS, c0, ck, m0 - J.pad, rows, tid);
         }
-        __syncthreads();
+        if constexpr (LW > 0)
+        {
+            // barrier #c, raw: the weight ring's requests stay in flight across it (__syncthreads would drain them: 1.1 us per chunk)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        else
+            __syncthreads();
 #ifdef ZV_STAMPS
         if (stamp_k < 10) { ZV_STAMP(stamp_k) stamp_k++; }
 #endif
         if (n_ok && !(ZV_DBGBITS(J.dbg) & 2))
         {
+            const char *ab_ = abase + (LW > 0 ? par * jobs.tile_bytes : 0);
             const half8 *wp = (const half8 *)J.w + ((size_t)ntl * K * nicb + (size_t)K * (c0 >> 4)) * 64 + lane;
             const size_t wseg = (size_t)K * nicb * 64;             // half8 units between consecutive output tiles
             // full chunks of 256 / 128 / 64 channels take the immediate-address loop (S = K*nkc is a multiple of 4 there
@@ -744,31 +987,32 @@ __global__ __launch_bounds__(256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void con
             if constexpr (SINGLE && NT == 1)
             {
                 if (ck == 256 && single256)
-                    mfma_taps_single256<MT>(acc, abase, dil * RS, wp, K, bring);
+                    mfma_taps_single256<MT>(acc, ab_, dil * RS, wp, K, bring);
                 else
-                    mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
+                    mfma_chunk<MT, NT>(acc, ab_, RS, dil, wp, wseg, K, ck >> 4);
             }
             else if constexpr (NT == 2)
             {
                 // the 64 x 64 wave tile keeps to loops with ONE set of four weight-fragment slots (168 registers: three
                 // workgroups per CU)
                 if (ck == 256 && J.ck == 256)
-                    mfma_taps_ring4<256, MT, NT>(acc, abase, dil * RS, wp, wseg, K);
+                    mfma_taps_ring4<256, MT, NT>(acc, ab_, dil * RS, wp, wseg, K);
                 else
-                    mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
+                    mfma_chunk<MT, NT>(acc, ab_, RS, dil, wp, wseg, K, ck >> 4);
             }
             else if (ck == 256 && J.ck == 256)
-                mfma_taps<256, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
+                mfma_taps<256, MT, NT, false>(acc, ab_, dil * RS, wp, wseg, K);
             else if (ck == 128 && J.ck == 128)
-                mfma_taps<128, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
+                mfma_taps<128, MT, NT, false>(acc, ab_, dil * RS, wp, wseg, K);
             else if (ck == 64 && J.ck == 64)
-                mfma_taps<64, MT, NT, false>(acc, abase, dil * RS, wp, wseg, K);
+                mfma_taps<64, MT, NT, false>(acc, ab_, dil * RS, wp, wseg, K);
             else
-                mfma_chunk<MT, NT>(acc, abase, RS, dil, wp, wseg, K, ck >> 4);
+                mfma_chunk<MT, NT>(acc, ab_, RS, dil, wp, wseg, K, ck >> 4);
         }
 #ifdef ZV_STAMPS
         if (stamp_k < 11) { ZV_STAMP(stamp_k) stamp_k++; }
 #endif
+        par ^= 1;
     }
 
     // ---------------- epilogue ----------------
@@ -858,7 +1102,9 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
                  (knob(ZV_STAMP_CIN) ? jobs.j[0].Cin_p == knob(ZV_STAMP_CIN) : jobs.j[0].Cin_p >= 1024);
 #endif
     // + dil rows: mfma_taps prefetches one tap past the end
-    const size_t lds = (size_t)round_up((BM + halo + dmax_) * (ck * 2 + 16), 16);
+    constexpr int LW = SINGLE ? ZV_SINGLE_LW : 0;
+    jobs.tile_bytes = round_up((BM + halo + dmax_) * (ck * 2 + 16), 16);
+    const size_t lds = (size_t)jobs.tile_bytes * (LW > 0 ? 2 : 1);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = conv1d_mfma_kernel<MT, WN, NT, SINGLE>;
     if (lds > 64 * 1024)
@@ -866,7 +1112,7 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, jobs);
+    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * LW), lds, s, jobs);
     return hipGetLastError();
 }
 

@@ -131,6 +131,7 @@ struct ConvJobs
     int     tps;                 // row tiles per segment (grid.x = tps * nseg)
     int     nt_begin;            // first output tile of this launch (the tiles before it belong to conv_gemm_kernel)
     int     order;               // conv_gemm_kernel: workgroup order (ZV_GEMM_ORDER: 0 plain, 1 one group per XCD, 2 the 9-tile group first)
+    int     tile_bytes;          // single-utterance form of conv1d_mfma_kernel: bytes of one of its two LDS tiles (set by the launcher)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
