@@ -234,7 +234,9 @@ def test_kernel_regimes_give_the_same_bits(ckpt):
                       # round 4: the fused batch kernels run on v_mfma_f32_16x16x32_f16, the generic conv kernel ("no_fuse") and the
                       # single-utterance whole-block kernel on 32x32x16: one k-ordered chain, two instruction shapes, the same bits
                       ("pair_mt4", {"ZV_PAIR_MT": "4", "ZV_FUSE256": "1"}),
-                      ("pair_no_ring_no_triple", {"ZV_PAIR64_RING": "0", "ZV_NO_TRIPLE": "1", "ZV_MERGE_ALWAYS": "1"})):
+                      ("pair_no_ring_no_triple", {"ZV_PAIR64_RING": "0", "ZV_NO_TRIPLE": "1", "ZV_MERGE_ALWAYS": "1"}),
+                      # the single-utterance conv form (loader waves, two LDS tiles) with its channel groups dealt / not dealt over the XCDs
+                      ("single_loop_everywhere_plain_grid", {"ZV_CONV_SINGLE": "2", "ZV_CONV_XCD": "0"}), ("plain_grid", {"ZV_CONV_XCD": "0"})):
         with capi.switches(**{k: int(v) for k, v in env.items()}):      # some switches are sampled when the model is built, some at every launch
             m = capi.Model(path, 0)
             outs[name] = m.vocode(mel)

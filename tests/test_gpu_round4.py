@@ -185,3 +185,32 @@ def test_fused_tails_and_one_launch_regulator_give_the_same_bits(ckpt):
                 assert np.array_equal(a_, b_), name
             for a_, b_ in zip(o[9], ref[9]):
                 assert np.array_equal(a_, b_), name
+
+
+def test_single_utterance_conv_forms_give_the_same_bits(ckpt):
+    """one utterance end to end under every form its generic convs can take — the loader-wave form (four waves stage chunk c + 1 into
+    the second LDS tile while four multiply chunk c) with its channel groups dealt over the XCDs or on a plain grid, for multi-chunk
+    convs only (default) or every conv, or never (the batch's form: every wave stages, then every wave multiplies): one accumulation
+    chain per output element whoever stages the tile, so the waveform, the frame count and every encoder tap are bit-equal"""
+    from zerovox_cpp_amd import capi, synth
+    path, g, _ = ckpt("medium")
+    ids, puncts, style = synth.encoder_inputs(g, 77, 128)
+    T = 512
+    ref = None
+    for name, sw in (("default", {}), ("plain_grid", dict(ZV_CONV_XCD=0)), ("every_conv", dict(ZV_CONV_SINGLE=2)),
+                     ("every_conv_plain_grid", dict(ZV_CONV_SINGLE=2, ZV_CONV_XCD=0)), ("never", dict(ZV_CONV_SINGLE=0))):
+        with capi.switches(**sw):
+            m = capi.Model(path, 0)
+            outs = []
+            for graph in (False, True):
+                m.set_graph_mode(graph)
+                w, nf = m.synthesize(ids, puncts, style, T)
+                e = m.encode(ids, puncts, style, T)
+                outs.append((w, nf, e["hidden"], e["logdur"], e["pitch"], e["energy"]))
+            m.close()
+        if ref is None:
+            ref = outs[0]
+        for o in outs:
+            assert o[1] == ref[1], name
+            for a_, b_ in zip(o[:1] + o[2:], ref[:1] + ref[2:]):
+                assert np.array_equal(a_, b_), name

@@ -835,12 +835,26 @@ __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 &&
     constexpr int LW = SINGLE ? ZV_SINGLE_LW : 0;          // loader waves (waves 4 .. 4 + LW - 1)
     constexpr int BM = 32 * MT * WM;
     const ConvJob &J = jobs.j[blockIdx.z];
+    // workgroup -> (row tile bx, channel group by of ny).  Single-utterance launches deal the channel groups over the XCDs (the
+    // hardware hands workgroup i to XCD i % 8): all row tiles of a channel group run on ONE XCD, whose L2 then holds that group's
+    // weight fragments (a 1 056 x 1 056 x 3 conv's 6.7 MB do not fit one XCD's 4 MB; with row tiles dealt over the XCDs every XCD
+    // streamed all of them from the memory side: scripts/frag_stream_bw.hip, 7-10 TB/s over the chip)
+    int bx = blockIdx.x, by = blockIdx.y, ny = gridDim.y;
+    if constexpr (SINGLE)
+        if (jobs.xcd_ny)
+        {
+            const int q = blockIdx.x >> 3, g = q / jobs.xcd_nx;
+            by = (blockIdx.x & 7) + 8 * g;
+            bx = q - g * jobs.xcd_nx;
+            ny = jobs.xcd_ny;
+            if (by >= ny) return;
+        }
 
     // workgroup -> (segment, row tile inside the segment)
-    const int useg = blockIdx.x / jobs.tps;
+    const int useg = bx / jobs.tps;
     const Seg sg = seg_at(jobs.segs, useg);
     const int L = sg.rows * jobs.rate;
-    const int m0 = (blockIdx.x - useg * jobs.tps) * BM;
+    const int m0 = (bx - useg * jobs.tps) * BM;
     if (m0 >= L) return;
     const size_t row0 = (size_t)sg.row0 * jobs.rate;
 
@@ -857,7 +871,7 @@ __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 &&
     // the output tiles are dealt evenly over the gridDim.y channel groups (33 tiles over 5 groups: 7 7 7 6 6, not 8 8 8 8 1 —
     // every workgroup stages its input tile for every chunk, however few of its waves have work)
     const int nt_span = ntiles - jobs.nt_begin;     // (tiles before nt_begin belong to conv_gemm_kernel)
-    const int gt0 = jobs.nt_begin + (int)((long)blockIdx.y * nt_span / gridDim.y), gt1 = jobs.nt_begin + (int)((long)(blockIdx.y + 1) * nt_span / gridDim.y);
+    const int gt0 = jobs.nt_begin + (int)((long)by * nt_span / ny), gt1 = jobs.nt_begin + (int)((long)(by + 1) * nt_span / ny);
     const int nt0 = gt0 + wn * NT;
     const bool n_ok = nt0 < gt1;
     // a wave whose second tile does not exist computes the tile before it twice and stores it once
@@ -894,7 +908,7 @@ __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 &&
     half8 bring[SINGLE ? 16 : 1];
     const bool single256 = SINGLE && NT == 1 && J.ck == 256 && Cin_p >= 256 && n_ok;
 #ifdef ZV_STAMPS
-    const int stamp_wg = blockIdx.x + gridDim.x * blockIdx.y;
+    const int stamp_wg = bx + jobs.tps * jobs.segs.nseg * by;
     int stamp_k = 1;
 #endif
     ZV_STAMP(0)
@@ -1103,6 +1117,14 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
 #endif
     // + dil rows: mfma_taps prefetches one tap past the end
     constexpr int LW = SINGLE ? ZV_SINGLE_LW : 0;
+    jobs.xcd_ny = 0;
+    if (SINGLE && knob(ZV_CONV_XCD) != 0)
+    {
+        // (see the kernel) grid.x = 8 XCDs x slots; slot q of XCD k = (channel group k + 8 (q / nx), row tile q % nx)
+        jobs.xcd_ny = grid.y;
+        jobs.xcd_nx = grid.x;
+        grid = dim3(8 * grid.x * ((grid.y + 7) / 8), 1, njobs);
+    }
     jobs.tile_bytes = round_up((BM + halo + dmax_) * (ck * 2 + 16), 16);
     const size_t lds = (size_t)jobs.tile_bytes * (LW > 0 ? 2 : 1);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

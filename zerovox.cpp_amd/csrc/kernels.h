@@ -132,6 +132,7 @@ struct ConvJobs
     int     nt_begin;            // first output tile of this launch (the tiles before it belong to conv_gemm_kernel)
     int     order;               // conv_gemm_kernel: workgroup order (ZV_GEMM_ORDER: 0 plain, 1 one group per XCD, 2 the 9-tile group first)
     int     tile_bytes;          // single-utterance form of conv1d_mfma_kernel: bytes of one of its two LDS tiles (set by the launcher)
+    int     xcd_ny, xcd_nx;      // single-utterance form: channel groups / row tiles of the launch when the groups are dealt over the XCDs (0: plain grid)
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif
