@@ -971,10 +971,11 @@ void Model::vocode_group(const Batch &bt, const float *d_mel, float *d_wav, int 
         // (conv -> lrelu -> conv -> + residual, xt kept in LDS), y ping-pongs between two buffers because a
         // workgroup's halo rows belong to its neighbours' output tiles.
         const ResPair &rp0 = voc_.pairs[((size_t)i * voc_.n_rb) * voc_.n_dil];
-        // 256-channel stage: the fused kernel needs all 256 xt channels in one workgroup, which leaves only
-        // ceil(L/54) workgroups per branch — measured slower than two unfused launches (480 workgroups) until the
-        // stage has enough rows to give every CU two of them (long / batched utterances)
-        const bool enough_rows = Cp != 256 || force_fuse256_ || (Lbatch / 54) * 3 >= 2L * n_cu;
+        // 256-channel stage: the fused kernel needs all 256 xt channels in one workgroup, which leaves few workgroups per
+        // branch for a short utterance — two unfused launches (480 workgroups at 512 frames) win below about a round
+        // of fused ones (round 4, on the 16 x 16 x 32 kernel, whole vocoder under graph replay: 128 frames 0.276 unfused /
+        // 0.291 fused ms, 256: 0.320 / 0.333, 512: 0.470 / 0.465, 1 024: 0.852 / 0.814)
+        const bool enough_rows = Cp != 256 || force_fuse256_ || (Lbatch / 54) * 3 >= (long)n_cu;
         const bool fused = !no_fuse_ && rp0.p1 != nullptr && enough_rows;
         const float *ycur[3] = {ub, ub, ub};
         const float *merged_sum = nullptr;
