@@ -1,4 +1,4 @@
-"""configs[2] (one 128-phoneme utterance, T = 512) in a loop, for kernel traces: python scripts/single.py [reps] [graph]"""
+"""configs[2] (one 128-phoneme utterance, T = 512) in a loop, for kernel traces: python scripts/single.py [reps] [graph] [N] [T]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
@@ -10,6 +10,7 @@ if not os.path.exists(ckpt):
     synth.write_checkpoint(ckpt, g, 1234)
 m = capi.Model(ckpt, 0)
 N, T = 128, 512
+if len(sys.argv) > 4: N, T = int(sys.argv[3]), int(sys.argv[4])
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ids, puncts, style = synth.encoder_inputs(g, 5, N)
 m.reserve(N, T)

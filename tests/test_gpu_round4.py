@@ -198,6 +198,7 @@ def test_single_utterance_conv_forms_give_the_same_bits(ckpt):
     T = 512
     ref = None
     for name, sw in (("default", {}), ("plain_grid", dict(ZV_CONV_XCD=0)), ("every_conv", dict(ZV_CONV_SINGLE=2)),
+                     ("cold_l2", dict(ZV_CONV_WARM=0)), ("cold_l2_plain_grid", dict(ZV_CONV_WARM=0, ZV_CONV_XCD=0)),
                      ("every_conv_plain_grid", dict(ZV_CONV_SINGLE=2, ZV_CONV_XCD=0)), ("never", dict(ZV_CONV_SINGLE=0))):
         with capi.switches(**sw):
             m = capi.Model(path, 0)

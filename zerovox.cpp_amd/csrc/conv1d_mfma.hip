@@ -275,7 +275,9 @@ struct StageRegs
 template <int U, int PRO, int NTH>
 __device__ __forceinline__ void stage_load_p(const StageSrc &J, int c0, int ck, int row_t0, int rows, int tid, StageRegs<U> &R)
 {
-    const int cols = ck >> 2, total = rows * cols, L = J.L;
+    // (an f16 operand tensor travels in 16-byte pieces of 8 channels, everything else in pieces of 4 channels)
+    constexpr int PW = PRO == PRO_RAW_F16 ? 8 : 4;
+    const int cols = ck / PW, total = rows * cols, L = J.L;
     int r = tid / cols, c4 = tid - r * cols;
     const int dr = NTH / cols, dc = NTH - dr * cols;
     if (dc == 0)
@@ -297,13 +299,9 @@ __device__ __forceinline__ void stage_load_p(const StageSrc &J, int c0, int ck, 
     {
         const int t = row_t0 + r;
         const bool inr = tid + u * NTH < total && t >= 0 && t < L;
-        const size_t off = (size_t)(inr ? t : 0) * J.ldx + c0 + c4 * 4;
+        const size_t off = (size_t)(inr ? t : 0) * J.ldx + c0 + c4 * PW;
         if constexpr (PRO == PRO_RAW_F16)
-        {
-            const uint2 h = *(const uint2 *)((const _Float16 *)J.x0 + off);
-            R.v[u].x = __uint_as_float(h.x);
-            R.v[u].y = __uint_as_float(h.y);
-        }
+            R.v[u] = *(const float4 *)((const _Float16 *)J.x0 + off);
         else
             R.v[u] = *(const float4 *)((const float *)J.x0 + off);
         r += dr;
@@ -315,7 +313,8 @@ template <int U, int PRO, int NTH>
 __device__ __forceinline__ void stage_store_p(const StageSrc &J, char *smem, int RS, int c0, int ck, int row_t0, int rows, int tid,
                                               const StageRegs<U> &R)
 {
-    const int cols = ck >> 2, total = rows * cols, L = J.L;
+    constexpr int PW = PRO == PRO_RAW_F16 ? 8 : 4;
+    const int cols = ck / PW, total = rows * cols, L = J.L;
     int r = tid / cols, c4 = tid - r * cols;
     const int dr = NTH / cols, dc = NTH - dr * cols;
     const bool hoist = dc == 0;
@@ -326,16 +325,18 @@ __device__ __forceinline__ void stage_store_p(const StageSrc &J, char *smem, int
         const int t = row_t0 + r;
         const bool live = tid + u * NTH < total;
         const bool inr = live && t >= 0 && t < L;
-        const int lofs = r * RS + c4 * 8;
-        if (live)
+        const int lofs = r * RS + c4 * 2 * PW;
+        if constexpr (PRO == PRO_RAW_F16)
+        {
+            if (live) *(float4 *)(smem + lofs) = inr ? R.v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        else if (live)
         {
             half4 h = {0, 0, 0, 0};
             if (inr)
             {
                 if constexpr (PRO == PRO_RAW_F16)
                 {
-                    const uint2 q = {__float_as_uint(R.v[u].x), __float_as_uint(R.v[u].y)};
-                    h = *(const half4 *)&q;
                 }
                 else
                 {
@@ -794,8 +795,13 @@ __device__ __forceinline__ void mfma_taps_single256(floatx16 (&acc)[MT][1], cons
 #ifdef ZV_STAMPS
 constexpr int ZV_STAMP_WGS = 1 << 17, ZV_STAMP_N = 12;
 __device__ unsigned long long zv_stamp_buf[(size_t)ZV_STAMP_WGS * ZV_STAMP_N];
+#ifdef ZV_STAMPS_LOADER
+#define ZV_STAMP_TID 256
+#else
+#define ZV_STAMP_TID 0
+#endif
 #define ZV_STAMP(k)                                                                                   \
-    if (jobs.stamp && threadIdx.x == 0 && stamp_wg < ZV_STAMP_WGS)                                    \
+    if (jobs.stamp && threadIdx.x == ZV_STAMP_TID && stamp_wg < ZV_STAMP_WGS)                         \
     {                                                                                                 \
         zv_stamp_buf[(size_t)stamp_wg * ZV_STAMP_N + (k)] = __builtin_amdgcn_s_memrealtime();         \
     }
@@ -828,6 +834,20 @@ __device__ __forceinline__ void tile_stats_store(const float (&v)[16], int t_fir
 // loop — the counted waits that keep eight fragments in flight are gone — and the wide decoder convs ran 3 % slower.)
 // (Measured dead end, round 3: two extra "loader" waves staging chunk c + 1 into a second LDS tile under the MFMA loop of chunk c:
 // decoder convs 311 -> 378 us; removed in round 4.)
+// Single-utterance convs: every row tile of a channel group walks the same weight stream in step, so each fragment is an L2 miss
+// for all of them together (a memory-side round trip per ring refill).  The group's row tiles sit on ONE XCD (see the kernels), so they
+// warm its L2 together first: workgroup `part` of `nparts` touches its slice of the group's weight bytes, one 4-byte load per
+// 128-byte line (64 lines = 8 KiB per wave instruction, 256 bytes returned).  The result is discarded; nothing waits for it.
+__device__ __forceinline__ void l2_warm(const void *base, size_t bytes, int part, int nparts, int tid, int nth)
+{
+    const size_t lines = (bytes + 127) >> 7;
+    const size_t per = (lines + nparts - 1) / nparts, l0 = (size_t)part * per;
+    const size_t l1 = l0 + per < lines ? l0 + per : lines;
+    unsigned sink = 0;
+    for (size_t l = l0 + tid; l < l1; l += nth) sink ^= *(const volatile unsigned *)((const char *)base + (l << 7));
+    asm volatile("" ::"v"(sink));
+}
+
 template <int MT, int WN, int NT, bool SINGLE = false>
 __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 && ZV_NT2_OCC == 3) ? 3 : 2) void conv1d_mfma_kernel(const ConvJobs jobs)
 {
@@ -878,6 +898,9 @@ __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 &&
     const int ntl = nt0 + NT <= gt1 ? nt0 : (gt1 - NT > 0 ? gt1 - NT : 0);
     const int rows = BM + (K - 1) * dil;
     const int RS = J.ck * 2 + 16;            // LDS row stride in bytes
+    if constexpr (SINGLE)
+        if (jobs.xcd_ny && jobs.warm)
+            l2_warm((const char *)J.w + (size_t)gt0 * K * nicb * 1024, (size_t)(gt1 - gt0) * K * nicb * 1024, bx, jobs.xcd_nx, tid, 256 + 64 * LW);
 
     StageSrc S;
     {
@@ -919,43 +942,86 @@ __global__ __launch_bounds__(SINGLE ? 256 + 64 * ZV_SINGLE_LW : 256, (NT == 2 &&
         {
             constexpr int NL = 64 * (LW > 0 ? LW : 1), UL = ZV_STAGE_ULW;
             const int ltid = tid - 256;
-            // a tile that fits the loaders' registers (and is one tensor) travels in two halves: tile c + 1 is REQUESTED before
-            // barrier #c — while the MFMA waves are still in chunk c - 1 — and written after it; the loaders' raw barrier does not
-            // wait for the vector-memory counter
+            // a tile that fits the loaders' registers (and is one tensor) travels in two halves, TWO tiles ahead: tile c + 2 is requested
+            // before barrier #c (into the register set tile c left), tile c + 1 — requested a whole chunk earlier — is written after
+            // it.  (One tile ahead, the request had only the loaders' wait at the barrier to land in: behind the MFMA waves' weight stream
+            // on the CU's vector-memory path a round trip is ~2.5 us and the MFMA waves waited 2.1 us per chunk for the loaders.)
+            // The loaders' raw barrier does not wait for the vector-memory counter.
             const bool split = J.pro != PRO_SUM3_ACT && rows * (J.ck >> 2) <= NL * UL && !(ZV_DBGBITS(J.dbg) & 1);
-            StageRegs<UL> R;
-            const int ck0 = Cin_p < J.ck ? Cin_p : J.ck;
-#define ZV_LOAD_(P) stage_load_p<UL, P, NL>(S, cn_, ckn_, m0 - J.pad, rows, ltid, R)
-#define ZV_STORE_(P) stage_store_p<UL, P, NL>(S, dst_, RS, cn_, ckn_, m0 - J.pad, rows, ltid, R)
+            StageRegs<UL> Ra, Rb;
+            const int nck = J.ck;
+            auto ckof = [&](int c) { return (Cin_p - c < nck) ? (Cin_p - c) : nck; };
+#define ZV_LOAD_(P) stage_load_p<UL, P, NL>(S, cn_, ckn_, m0 - J.pad, rows, ltid, R_)
+#define ZV_STORE_(P) stage_store_p<UL, P, NL>(S, dst_, RS, cn_, ckn_, m0 - J.pad, rows, ltid, R_)
+#define ZV_LD_TILE(REGS, c)                                        \
+    if ((c) < Cin_p)                                               \
+    {                                                              \
+        StageRegs<UL> &R_ = REGS;                                  \
+        const int cn_ = (c), ckn_ = ckof(c);                       \
+        ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_LOAD_)                     \
+    }
+#define ZV_ST_TILE(REGS, c, buf)                                   \
+    if ((c) < Cin_p)                                               \
+    {                                                              \
+        const StageRegs<UL> &R_ = REGS;                            \
+        const int cn_ = (c), ckn_ = ckof(c);                       \
+        char *dst_ = smem + (buf) * jobs.tile_bytes;               \
+        ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_STORE_)                    \
+    }
+#define ZV_RAW_BARRIER()                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    __builtin_amdgcn_s_barrier();                                  \
+    asm volatile("" ::: "memory");
             if (split)
             {
-                const int cn_ = 0, ckn_ = ck0;
-                char *dst_ = smem;
-                ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_LOAD_)
-                ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_STORE_)
-            }
-            int par = 0;
-            for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
-            {
-                const int ck = (Cin_p - c0 < J.ck) ? (Cin_p - c0) : J.ck;
-                const int cn_ = c0 + J.ck, ckn_ = (Cin_p - cn_ < J.ck) ? (Cin_p - cn_) : J.ck;
-                char *dst_ = smem + (par ^ 1) * jobs.tile_bytes;
-                if (!split)
+                ZV_LD_TILE(Ra, 0)
+                ZV_LD_TILE(Rb, nck)
+                ZV_ST_TILE(Ra, 0, 0)
+                // chunks in pairs: tile c lives in Ra for even chunk indices, in Rb for odd ones
+#ifdef ZV_STAMPS_LOADER
+                const int stamp_wg = bx + jobs.tps * jobs.segs.nseg * by;
+                int lk = 1;
+                ZV_STAMP(0)
+#define ZV_LSTAMP() if (lk < 11) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ZV_STAMP(lk) lk++; }
+#else
+#define ZV_LSTAMP()
+#endif
+                for (int c0 = 0; c0 < Cin_p; c0 += 2 * nck)
                 {
+                    ZV_LD_TILE(Ra, c0 + 2 * nck)
+                    ZV_LSTAMP()
+                    ZV_RAW_BARRIER()                   // barrier of chunk c0
+                    ZV_LSTAMP()
+                    ZV_ST_TILE(Rb, c0 + nck, 1)
+                    ZV_LSTAMP()
+                    if (c0 + nck >= Cin_p) break;
+                    ZV_LD_TILE(Rb, c0 + 3 * nck)
+                    ZV_LSTAMP()
+                    ZV_RAW_BARRIER()                   // barrier of chunk c0 + ck
+                    ZV_LSTAMP()
+                    ZV_ST_TILE(Ra, c0 + 2 * nck, 0)
+                    ZV_LSTAMP()
+                }
+#ifdef ZV_STAMPS_LOADER
+                ZV_STAMP(11)
+#endif
+#undef ZV_LSTAMP
+            }
+            else
+            {
+                int par = 0;
+                for (int c0 = 0; c0 < Cin_p; c0 += J.ck)
+                {
+                    const int ck = ckof(c0);
                     if (!(ZV_DBGBITS(J.dbg) & 1))
                         stage_tile<ZV_STAGE_ULW, NL>(J.pro, S, smem + par * jobs.tile_bytes, RS, c0, ck, m0 - J.pad, rows, ltid);
                     __syncthreads();
+                    par ^= 1;
                 }
-                else
-                {
-                    if (cn_ < Cin_p) { ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_LOAD_) }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's writes of tile c have landed
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (cn_ < Cin_p) { ZV_STAGE_SPLIT_SWITCH(J.pro, ZV_STORE_) }
-                }
-                par ^= 1;
             }
+#undef ZV_RAW_BARRIER
+#undef ZV_ST_TILE
+#undef ZV_LD_TILE
 #undef ZV_LOAD_
 #undef ZV_STORE_
             return;
@@ -1118,6 +1184,7 @@ static hipError_t launch_cfg(hipStream_t s, ConvJobs &jobs, int njobs, int Lmax,
     // + dil rows: mfma_taps prefetches one tap past the end
     constexpr int LW = SINGLE ? ZV_SINGLE_LW : 0;
     jobs.xcd_ny = 0;
+    jobs.warm = knob(ZV_CONV_WARM) != 0;
     if (SINGLE && knob(ZV_CONV_XCD) != 0)
     {
         // (see the kernel) grid.x = 8 XCDs x slots; slot q of XCD k = (channel group k + 8 (q / nx), row tile q % nx)

@@ -133,6 +133,7 @@ struct ConvJobs
     int     order;               // conv_gemm_kernel: workgroup order (ZV_GEMM_ORDER: 0 plain, 1 one group per XCD, 2 the 9-tile group first)
     int     tile_bytes;          // single-utterance form of conv1d_mfma_kernel: bytes of one of its two LDS tiles (set by the launcher)
     int     xcd_ny, xcd_nx;      // single-utterance form: channel groups / row tiles of the launch when the groups are dealt over the XCDs (0: plain grid)
+    int     warm;                // single-utterance forms: the row tiles of a channel group warm their XCD's L2 with the group's weights first
 #ifdef ZV_STAMPS
     int     stamp;               // diagnostic build: this launch writes phase stamps
 #endif

@@ -30,6 +30,7 @@ namespace zv
     X(ZV_GEMM_ORDER, 2)        /* conv_gemm_kernel's workgroup order: 0 plain (group fastest), 2 the 9-tile group first */ \
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
     X(ZV_CONV_XCD, 1)          /* single-utterance conv launches: a channel group's row tiles all on one XCD (its L2 holds the group's weights); 0 = row tiles dealt over the XCDs */ \
+    X(ZV_CONV_WARM, 1)         /* single-utterance convs: a channel group's row tiles touch the group's weights (one load per 128-byte line) before they start: L2 hits instead of a miss shared by all of them per fragment */ \
     X(ZV_BLOCK64, 3)           /* 64-channel stage of a batch: branches with at most that many taps run their first two dilation pairs in one launch (resblock_block64_kernel); 0 never, negative: at any length */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
     X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always, 3 always on 512-row tiles: whole-block kernel with its weights in LDS */                      \

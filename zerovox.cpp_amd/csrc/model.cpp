@@ -1314,12 +1314,15 @@ void Model::decode_dev(const Batch &bt, const float *d_hidden, const float *d_st
     _Float16 *xa16 = arena_.take_n<_Float16>(L * CAT), *t16 = arena_.take_n<_Float16>(L * B), *xr16 = arena_.take_n<_Float16>(L * CAT);
     const double Ld = (double)L;
     // Two ways to feed a conv its normalised operand, same bits (tests): (a) the conv normalises while it stages its
-    // input tile (PRO_NORM_ACT) — no extra launch, right for a single utterance where every launch is latency; (b) one
+    // input tile (PRO_NORM_ACT) — no extra launch, right for a very short utterance where every launch is latency; (b) one
     // pass writes the f16 operand (launch_norm_act_f16) and the conv copies it (PRO_RAW_F16) — right when launches have
     // many rounds of workgroups: a 1 056-wide conv stages every input tile 9 times (once per group of 128 output
     // channels), so (a) repeats the f32 prologue 9 times and reads twice the bytes.
     const int pre_env = knob(ZV_DEC_PREPASS);      // test / A-B hook
-    const bool prepass = pre_env >= 0 ? pre_env != 0 : (size_t)bt.t_max * bt.nseg >= 4096;
+    // (round 4: with the single-utterance conv form's loader waves the pass pays from 256 frames on — it takes the statistics launch's
+    // place and leaves the loaders a plain copy: one utterance of 128 / 256 / 512 / 1 024 frames 1.32 / 1.345 / 1.62 / 2.16 ms fused,
+    // 1.33 / 1.33 / 1.58 / 2.07 ms with the pass)
+    const bool prepass = pre_env >= 0 ? pre_env != 0 : (size_t)bt.t_max * bt.nseg >= 256;
 
     // D2: all ten AdaIN fc layers at once for every utterance's style vector            (src/stylettsdec.cpp:175-189)
     ZV_LAUNCH("dec_adain_fc", 4.0 * dec_.fc_out * (Ed + 2), 2.0 * S * dec_.fc_out * Ed,
