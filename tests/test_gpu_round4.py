@@ -215,3 +215,28 @@ def test_single_utterance_conv_forms_give_the_same_bits(ckpt):
             assert o[1] == ref[1], name
             for a_, b_ in zip(o[:1] + o[2:], ref[:1] + ref[2:]):
                 assert np.array_equal(a_, b_), name
+
+
+def test_single_utterance_forms_on_ragged_sizes(ckpt):
+    """the loader-wave conv form against the batch's form on utterances whose sizes hit the tile edges (1 .. 300 phonemes, 1 .. 1 500 frames:
+    one row tile or many, chunks of 256 / 32 / 16 channels, the operand pre-pass on either side of its 256-frame threshold), eager and as a graph"""
+    from zerovox_cpp_amd import capi, synth
+    path, g, _ = ckpt("medium")
+    rng = np.random.default_rng(5)
+    a = capi.Model(path, 0)
+    try:
+        with capi.switches(ZV_CONV_SINGLE=0):
+            b = capi.Model(path, 0)
+            cases = []
+            for it, T in enumerate([1, 7, 31, 33, 64, 100, 255, 256, 257, 400, 777, 1500]):
+                n = int(rng.integers(1, 300))
+                ids, puncts, style = synth.encoder_inputs(g, 2100 + it, n)
+                cases.append((ids, puncts, style, T) + b.synthesize(ids, puncts, style, T))
+            b.close()
+        for graph in (False, True):
+            a.set_graph_mode(graph)
+            for ids, puncts, style, T, wb, nfb in cases:
+                w, nf = a.synthesize(ids, puncts, style, T)
+                assert nf == nfb and np.array_equal(w, wb), (len(ids), T, graph)
+    finally:
+        a.close()
