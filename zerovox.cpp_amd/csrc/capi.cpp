@@ -400,7 +400,8 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
     bt.n_rows = (size_t)bt.nseg * bt.n_max;
     bt.t_rows = (size_t)bt.nseg * bt.t_max;
     // device block: [frame counts][inputs: token table | frame table | ids | puncts | styles][hidden][mel][wav]
-    const size_t b_tab = al((size_t)bt.nseg * sizeof(zv::Seg)), b_ids = al(bt.n_rows * 4), b_sty = al((size_t)bt.nseg * E * 4);
+    // (tables: one entry per utterance + one that spans all of them, see Batch::tokens_merged)
+    const size_t b_tab = al((size_t)(bt.nseg + 1) * sizeof(zv::Seg)), b_ids = al(bt.n_rows * 4), b_sty = al((size_t)bt.nseg * E * 4);
     const size_t b_in = 2 * b_tab + 2 * b_ids + b_sty;
     const size_t b_nf = al((size_t)bt.nseg * 4), b_hid = al(bt.t_rows * E * 4), b_mel = al(bt.t_rows * Mm * 4),
                  b_wav = al(bt.t_rows * hop * 4);
@@ -439,6 +440,8 @@ static void batch_enqueue(zv_model *m, int lane, uint32_t n_utt, const int32_t *
             n0 += n;
             t0 += t;
         }
+        h_tok[n_utt] = zv::Seg{0, n0, n0, 0};
+        h_frm[n_utt] = zv::Seg{0, t0, 0, 0};
     }
     int32_t *h_nf = (int32_t *)(pin + b_in);
     char *h_wav = pin + b_in + b_nf;

@@ -31,6 +31,7 @@ namespace zv
     X(ZV_PAIR_MT, 0)           /* 2 / 3 / 4: tile height of the pair kernels */                                                       \
     X(ZV_CONV_XCD, 1)          /* single-utterance conv launches: a channel group's row tiles all on one XCD (its L2 holds the group's weights); 0 = row tiles dealt over the XCDs */ \
     X(ZV_CONV_WARM, 1)         /* single-utterance convs: a channel group's row tiles touch the group's weights (one load per 128-byte line) before they start: L2 hits instead of a miss shared by all of them per fragment */ \
+    X(ZV_LINEAR_MERGED, 1)     /* the encoder's per-token layers of a batch (linear, 1-tap conv, plain LayerNorm) over all token rows as one dense segment (0: row tiles per utterance) */ \
     X(ZV_BLOCK64, 3)           /* 64-channel stage of a batch: branches with at most that many taps run their first two dilation pairs in one launch (resblock_block64_kernel); 0 never, negative: at any length */ \
     X(ZV_PAIR64_RING, 1)       /* 0 never, 1 batches, 2 always: 64-channel pair kernel with the weights through an LDS ring */        \
     X(ZV_TRIPLE_V2, 1)         /* 0 never, 1 batches, 2 always, 3 always on 512-row tiles: whole-block kernel with its weights in LDS */                      \

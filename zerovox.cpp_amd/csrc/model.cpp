@@ -1525,6 +1525,7 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
     arena_require(arena_bytes_for(bt.n_rows, bt.t_rows, bt.nseg));
     arena_.used = 0;
     const Segs tk = bt.tokens(), fr = bt.frames();
+    const Segs tkm = knob(ZV_LINEAR_MERGED) != 0 ? bt.tokens_merged() : tk;      // the per-token layers (linear, 1-tap conv, plain LayerNorm) see one dense segment
     const int Ed = (int)E(), H = hp.encoder_head, dk = Ed / H;
     const size_t n = bt.n_rows;
     const double nd = (double)n;
@@ -1567,13 +1568,13 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
         layer_no++;
         if (dbg_here || dbg_mha) dbg_inject(x, Ed, Ed, n);
         ZV_LAUNCH("enc_linear", 4.0 * (3.0 * Ed * Ed + 4.0 * nd * Ed), 6.0 * nd * Ed * Ed,
-                  launch_linear(stream, x, Ed, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr, tk));
+                  launch_linear(stream, x, Ed, Ed, Ly.qkvW, Ly.qkvB, 3 * Ed, qkv, 3 * Ed, nullptr, tkm));
         ZV_LAUNCH("enc_attention", 16.0 * nd * Ed, 4.0 * nd * bt.n_max * Ed,
                   launch_attention(stream, qkv, qkv + Ed, qkv + 2 * Ed, 3 * Ed, H, dk, inv_t, o, Ed, tk));
         ZV_LAUNCH("enc_linear", 4.0 * (1.0 * Ed * Ed + 2.0 * nd * Ed), 2.0 * nd * Ed * Ed,
-                  launch_linear(stream, o, Ed, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr, tk));
+                  launch_linear(stream, o, Ed, Ed, Ly.fcW, Ly.fcB, Ed, f, Ed, nullptr, tkm));
         ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
-                  launch_add_layernorm(stream, f, Ed, x, Ed, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed, tk));
+                  launch_add_layernorm(stream, f, Ed, x, Ed, Ed, Ed, Ly.ln1w, Ly.ln1b, 1e-5f, y, Ed, tkm));
         if (dbg_mha)
         {
             dbg_extract(y, Ed, Ed, n);
@@ -1592,7 +1593,8 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
             b.x0 = hh;
             b.pro = PRO_RAW_F16;
             b.out = f;
-            conv(&b, 1, tk, 1, "enc_conv", conv_bytes(nd, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(nd, Ly.w1.Cout, Ed, Ly.w2.K));
+            // (a 1-tap conv is per token: like the linear layers it takes the batch as one dense segment)
+            conv(&b, 1, Ly.w2.K == 1 ? tkm : tk, 1, "enc_conv", conv_bytes(nd, Ly.w1.Cout, Ed, Ly.w2.K, false), conv_flops(nd, Ly.w1.Cout, Ed, Ly.w2.K));
         }
         // (the last layer's LayerNorm also adds the style vector: features = encoder output + style_embed, :550-552)
         if (tails && layer_no == (int)enc_.layers.size())
@@ -1601,7 +1603,7 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
                                             nullptr, nullptr, 0, 0, nullptr, 0, nullptr));
         else
             ZV_LAUNCH("enc_layernorm", 12.0 * nd * Ed, 8.0 * nd * Ed,
-                      launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tk));
+                      launch_add_layernorm(stream, f, Ed, y, Ed, Ed, Ed, Ly.ln2w, Ly.ln2b, 1e-5f, x, Ed, tkm));
         if (dbg_here || dbg_ffn)
         {
             dbg_extract(x, Ed, Ed, n);
@@ -1628,7 +1630,7 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
         a.out = va;
         conv(&a, 1, tk, 1, "enc_conv", conv_bytes(nd, Ed, v.V, 3, false), conv_flops(nd, Ed, v.V, 3));
         ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
-                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp, tk));
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l1w, v.l1b, 1e-5f, vb, Vp, tkm));
         ConvJob b = job(v.c2);
         b.x0 = vb;
         b.pad = 1;                                              // literal 1 in the reference (:417)
@@ -1644,7 +1646,7 @@ Model::EncoderTaps Model::encode_dev(const Batch &bt, const int32_t *d_ids, cons
             return;
         }
         ZV_LAUNCH("enc_layernorm", 8.0 * nd * v.V, 8.0 * nd * v.V,
-                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tk));
+                  launch_add_layernorm(stream, va, Vp, nullptr, 0, v.V, Vp, v.l2w, v.l2b, 1e-5f, vb, Vp, tkm));
         ZV_LAUNCH("enc_rowdot", 4.0 * nd * v.V, 2.0 * nd * v.V, launch_rowdot(stream, vb, Vp, v.V, v.lw, v.lb, out, tk));
         if (dbg_here) dbg_extract(out, 1, 1, n);
         if (emb && !dbg_layer.done)

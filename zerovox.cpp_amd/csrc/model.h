@@ -74,6 +74,9 @@ struct Batch
         return b;
     }
     Segs tokens() const { return Segs{d_tok, nseg, n_max, tok1}; }
+    // every token row of the batch as ONE segment (table entry nseg: rows [0, sum of phonemes)) — for the per-token layers, whose row
+    // tiles then pack the utterances densely instead of padding every utterance to a tile
+    Segs tokens_merged() const { return d_tok ? Segs{d_tok + nseg, 1, (int)n_rows, tok1} : tokens(); }
     Segs frames() const { return Segs{d_frm, nseg, t_max, frm1}; }
 };
 
